@@ -1,0 +1,190 @@
+/*
+ * sxe.h -- C ABI of libsxe_hip.so, the MI355X (gfx950) raster/shade path.
+ *
+ * The reference renderer (matthew-russo/renderer) has no FFI: its seam is the crate-private Rust
+ * trait `Drawer<B>` (src/renderer/drawer.rs:26-31) plus `Presenter<B>` (src/renderer/presenter.rs:16-22).
+ * Every entry point below names the reference interface it stands in for.  All pointer arguments
+ * are borrowed for the duration of the call only (the reference takes its arguments by value,
+ * src/renderer/drawer.rs:458,496,507); the library copies what it keeps.
+ *
+ * Threading: a context is externally synchronised (one caller at a time, like the reference's
+ * single engine thread, src/main.rs:143); distinct contexts are independent.  Each context owns
+ * one HIP stream on one device.
+ *
+ * Errors: every function returns 0 or a negative SXE_E_* code and never aborts the process
+ * (the reference panics instead: src/renderer/drawer.rs:453, src/renderer/types.rs:51).
+ */
+#ifndef SXE_H
+#define SXE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SXE_OK 0
+#define SXE_E_INVALID (-1)  /* bad argument or scene */
+#define SXE_E_DEVICE (-2)   /* a HIP call failed; see sxe_last_error */
+#define SXE_E_CAPACITY (-3) /* a stated limit was exceeded */
+#define SXE_E_STATE (-4)    /* call order violated (e.g. draw before update_drawables) */
+
+/* fragment shading variants: standard.frag:12 (default), standard.frag:13 (commented
+ * alternative), ui.frag:12 */
+#define SXE_SHADE_TEXTURE 0u
+#define SXE_SHADE_VERTEX_COLOR 1u
+#define SXE_SHADE_COLOR_TIMES_TEXTURE 2u
+
+#define SXE_FLAG_WRITE_COVERAGE 1u /* keep a per-pixel primitive-id buffer (parity tests) */
+#define SXE_FLAG_TIMING 2u         /* bracket every kernel with HIP events (sxe_get_timings) */
+
+#define SXE_MAX_DIM 8192u          /* width and height limit (8K frames fit) */
+#define SXE_MAX_PRIMS (1u << 29)   /* triangles per frame */
+
+typedef struct sxe_ctx sxe_ctx;
+
+/* src/primitives/vertex.rs:2-6; offsets 0/12/24, stride 32 as hard-coded at
+ * src/renderer/drawer.rs:665-696. */
+typedef struct {
+    float pos[3];
+    float color[3];
+    float uv[2];
+} sxe_vertex;
+
+/* src/components/transform.rs:16-21; rotation is a quaternion in cgmath memory order s,x,y,z. */
+typedef struct {
+    float position[3];
+    float scale[3];
+    float rotation[4];
+} sxe_transform;
+
+/* What GfxDrawer::new receives (src/renderer/drawer.rs:55) plus the constants it hard-codes:
+ * viewport extent (src/renderer/presenter.rs:373-383), perspective parameters
+ * (src/renderer/drawer.rs:248-253), clear colour (:307). */
+typedef struct {
+    uint32_t width, height;
+    float fov_deg, z_near, z_far;
+    float clear[4];
+    int32_t device;                  /* HIP device ordinal */
+    uint32_t n_images;               /* swapchain images (src/renderer/presenter.rs:440) */
+    uint32_t scissor_y0, scissor_y1; /* rows [y0,y1) this context renders (sort-first shard);
+                                        0,0 means the whole frame */
+    uint32_t shading;                /* SXE_SHADE_* */
+    uint32_t flags;                  /* SXE_FLAG_* */
+} sxe_config;
+
+/* RGBA8 texels, sRGB-encoded colour, tightly packed rows: what TextureData::load produces
+ * (src/renderer/types.rs:158-188) after JPEG decoding, which is outside this library. */
+typedef struct {
+    const uint8_t *rgba;
+    uint32_t width, height;
+} sxe_texture_desc;
+
+/* src/primitives/drawable.rs:7-12 with the mesh inlined (src/components/mesh.rs:4-9). */
+typedef struct {
+    const sxe_vertex *vertices;
+    uint32_t n_vertices;
+    const uint32_t *indices; /* mesh-local, triangle list */
+    uint32_t n_indices;
+    sxe_transform transform;
+    int32_t texture;   /* index into the table given to sxe_set_textures */
+    uint32_t rendered; /* src/components/mesh.rs:8 */
+} sxe_drawable;
+
+typedef struct {
+    const sxe_vertex *vertices;
+    uint32_t n_vertices;
+    const uint32_t *indices;
+    uint32_t n_indices;
+} sxe_mesh_desc;
+
+typedef struct {
+    uint32_t mesh;
+    int32_t texture;
+    uint32_t rendered;
+    sxe_transform transform;
+} sxe_instance;
+
+/* Per-kernel device times of the last synchronised frame, milliseconds (needs SXE_FLAG_TIMING). */
+typedef struct {
+    float transform_ms, object_ms, setup_count_ms, scan_ms, setup_emit_ms, raster_shade_ms, frame_ms;
+} sxe_timings;
+
+/* Work counters of the last synchronised frame. */
+typedef struct {
+    uint64_t prims;        /* triangles submitted */
+    uint64_t records;      /* record slots reserved (surviving triangles incl. clip fans) */
+    uint64_t bin_entries;  /* (triangle, tile) pairs */
+    uint64_t tiles;        /* screen tiles rendered */
+    uint64_t instance_vertices;
+    uint64_t objects;
+    uint32_t tile_size;
+    uint32_t redraws;      /* frames re-rendered after growing a work buffer */
+} sxe_frame_stats;
+
+/* ---- lifetime: GfxDrawer::new / Drop (src/renderer/drawer.rs:55-160,360-388) ---- */
+void sxe_default_config(sxe_config *cfg, uint32_t width, uint32_t height);
+int sxe_create(const sxe_config *cfg, sxe_ctx **out);
+void sxe_destroy(sxe_ctx *ctx);
+/* Message of the last failure on this context (or of the last failed sxe_create when ctx is NULL). */
+const char *sxe_last_error(const sxe_ctx *ctx);
+const char *sxe_version(void);
+
+/* ---- scene: Drawer::update_drawables (src/renderer/drawer.rs:458-494) ---- */
+/* generate_images (src/renderer/drawer.rs:216-236): replaces the whole texture table.  Textures
+ * must be opaque (alpha 255 everywhere), as every JPEG-derived reference texture is. */
+int sxe_set_textures(sxe_ctx *ctx, const sxe_texture_desc *textures, uint32_t n);
+/* One mesh per drawable, drawn once, as the reference stores them (src/renderer/drawer.rs:173-193). */
+int sxe_update_drawables(sxe_ctx *ctx, const sxe_drawable *drawables, uint32_t n);
+/* Same scene contract with shared meshes; lifts the reference's 1024-object cap
+ * (src/renderer/allocator.rs:311-318). */
+int sxe_update_instances(sxe_ctx *ctx, const sxe_mesh_desc *meshes, uint32_t n_meshes,
+                         const sxe_instance *instances, uint32_t n_instances);
+
+/* ---- per frame ---- */
+/* Drawer::update_uniforms (src/renderer/drawer.rs:496-505): n column-major mat4, caller order. */
+int sxe_update_uniforms(sxe_ctx *ctx, const float *models, uint32_t n);
+/* fetch_uniforms' Transform::to_ubo loop (src/main.rs:237-244, src/components/transform.rs:69-80)
+ * run on the device: uploads n transforms and derives the model matrices there. */
+int sxe_update_transforms(sxe_ctx *ctx, const sxe_transform *transforms, uint32_t n);
+/* Rotation::run (src/systems/rotation.rs:26-37) on the device-resident transforms, with a
+ * counter-based PRNG in place of thread_rng and a caller-supplied frame delta in ms. */
+int sxe_rotation_system(sxe_ctx *ctx, uint64_t seed, uint32_t frame, float delta_ms);
+/* Drawer::update_camera (src/renderer/drawer.rs:507-518). */
+int sxe_update_camera(sxe_ctx *ctx, const sxe_transform *camera);
+/* The same upload with caller-built matrices (column-major view, proj). */
+int sxe_update_camera_matrices(sxe_ctx *ctx, const float *view, const float *proj);
+/* Drawer::draw (src/renderer/drawer.rs:412-456): enqueue one frame into image `image_index`;
+ * asynchronous on the context's stream. */
+int sxe_draw(sxe_ctx *ctx, uint32_t image_index);
+/* The fence wait of src/renderer/drawer.rs:416-424.  Reports deferred device-side failures. */
+int sxe_sync(sxe_ctx *ctx);
+
+/* ---- readback: stands in for Presenter::present (src/renderer/presenter.rs:415-430) ---- */
+int sxe_read_color(sxe_ctx *ctx, uint32_t image_index, uint8_t *rgba, size_t size_bytes);
+int sxe_read_depth(sxe_ctx *ctx, uint32_t image_index, float *depth, size_t size_bytes);
+int sxe_read_coverage(sxe_ctx *ctx, uint32_t image_index, uint32_t *prim_ids, size_t size_bytes);
+/* gl_Position of every vertex (standard.vert:28) in the layout of the reference's concatenated
+ * vertex buffer (drawables in caller order, src/renderer/drawer.rs:173-179); 4 floats each. */
+int sxe_read_clip_positions(sxe_ctx *ctx, float *clip, size_t size_bytes);
+int sxe_read_models(sxe_ctx *ctx, float *models, size_t size_bytes);
+int sxe_read_transforms(sxe_ctx *ctx, sxe_transform *transforms, size_t size_bytes);
+/* Device address of an image's RGBA8 rows (for a zero-copy RCCL tile gather). */
+int sxe_color_device_ptr(sxe_ctx *ctx, uint32_t image_index, void **ptr);
+int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
+int sxe_get_stats(sxe_ctx *ctx, sxe_frame_stats *out);
+
+/* ---- host-side Transform / camera maths (no device needed) ---- */
+void sxe_transform_identity(sxe_transform *t);                           /* transform.rs:24-30 */
+void sxe_transform_translate(sxe_transform *t, float x, float y, float z); /* transform.rs:33-35 */
+void sxe_transform_rotate(sxe_transform *t, float x, float y, float z);  /* transform.rs:37-46 */
+void sxe_transform_to_model(const sxe_transform *t, float model[16]);    /* transform.rs:69-80 */
+/* update_camera_uniform_buffer_object (src/renderer/drawer.rs:242-258). */
+void sxe_camera_matrices(const sxe_transform *camera, float fov_deg, float aspect, float z_near,
+                         float z_far, float view[16], float proj[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

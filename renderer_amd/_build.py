@@ -1,0 +1,36 @@
+"""Builds renderer_amd/libsxe_hip.so with hipcc for gfx950 (in-tree, so it ships with the tree)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsxe_hip.so")
+SOURCES = ["sxe_api.hip", "sxe_kernels.hip"]
+HEADERS = ["sxe_internal.h", "sxe_math.h", "sxe_srgb_tables.h", os.path.join("..", "..", "include", "sxe.h")]
+
+# -ffp-contract=off: the kernels and the host maths must round every operation separately
+# (the parity contract); gfx950 only, no other offload target.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+               "-Wall", "-Wno-unused-function"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,847 @@
+// sxe_api.hip -- host side of libsxe_hip: the context, scene upload, per-frame submission and
+// readback behind the C ABI declared in include/sxe.h.
+//
+// The context plays the part of the reference's GfxDrawer (src/renderer/drawer.rs:33-52): it owns
+// the vertex/index buffers, the per-object uniform data, the camera matrices, the texture table
+// and the render targets.  There is no CPU rendering path: every entry point that needs the GPU
+// fails with SXE_E_DEVICE when HIP cannot provide one.
+#include "sxe_internal.h"
+#include "sxe_srgb_tables.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace sxe;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n; else p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Image {
+    DevBuf<uint8_t> color;
+    DevBuf<float> depth;
+    DevBuf<uint32_t> prim;
+    bool drawn = false;
+};
+
+enum { EV_BEGIN = 0, EV_OBJECT, EV_COUNT, EV_SCAN, EV_EMIT, EV_RASTER, EV_N };
+
+} // namespace
+
+struct sxe_ctx {
+    sxe_config cfg;
+    FrameGeom g;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    bool have_scene = false, have_camera = false;
+    uint32_t n_objects = 0, n_draws = 0, n_blocks = 0, n_vblocks = 0, n_meshes = 0, n_textures = 0;
+    uint64_t n_prims = 0, n_inst_vertices = 0;
+    DevBuf<sxe_vertex> vertices;
+    DevBuf<float> pos_x, pos_y, pos_z; // SoA copies for the stand-alone vertex kernel
+    DevBuf<uint32_t> indices;
+    DevBuf<MeshDev> meshes;
+    DevBuf<InstDev> insts;
+    DevBuf<BlockDesc> blocks;
+    DevBuf<VBlockDesc> vblocks;
+    DevBuf<float> models, pvm;
+    DevBuf<sxe_transform> transforms;
+    bool have_transforms = false;
+    DevBuf<uint8_t> texels;
+    DevBuf<TexDev> textab;
+    Mat4 view, proj, pv;
+
+    // per-frame work buffers
+    DevBuf<uint32_t> blk_count, blk_base, tile_counters /* count | fill */, tile_off, bins;
+    DevBuf<RastRec> rast;
+    DevBuf<ShadeRec> shade;
+    DevBuf<ColorRec> color;
+    DevBuf<FrameCounters> counters;
+    DevBuf<float4> clip;
+    FrameCounters *h_counters = nullptr; // pinned
+    size_t rec_capacity = 0, bin_capacity = 0;
+
+    std::vector<Image> images;
+    int last_image = -1;
+    bool frame_pending = false;
+    bool transform_timed = false;
+    hipEvent_t ev[EV_N] = {};
+    hipEvent_t ev_tr[2] = {};
+    sxe_timings timings = {};
+    sxe_frame_stats stats = {};
+    uint32_t redraws = 0;
+};
+
+namespace {
+
+int fail(sxe_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define SXE_HIP(c, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((c), SXE_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+uint32_t srgb_encode_host(float x)
+{
+    uint32_t n = 0;
+    for (int k = 0; k < 255; ++k) n += (SXE_SRGB_ENCODE_THR[k] <= x) ? 1u : 0u;
+    return n;
+}
+
+uint32_t unorm8_host(float a)
+{
+    if (!(a > 0.0f)) a = 0.0f;
+    if (a > 1.0f) a = 1.0f;
+    return (uint32_t)(int)rintf(a * 255.0f);
+}
+
+FrameGeom make_geom(const sxe_config &cfg)
+{
+    FrameGeom g;
+    g.width = cfg.width;
+    g.height = cfg.height;
+    g.sy0 = cfg.scissor_y0;
+    g.sy1 = cfg.scissor_y1;
+    g.tiles_x = (cfg.width + kTile - 1) / kTile;
+    g.tile_row0 = g.sy0 / kTile;
+    const uint32_t last_row = (g.sy1 > g.sy0) ? (g.sy1 - 1) / kTile : g.tile_row0;
+    g.n_tile_rows = (g.sy1 > g.sy0) ? last_row - g.tile_row0 + 1 : 0;
+    g.n_tiles = g.tiles_x * g.n_tile_rows;
+    g.half_w = (float)cfg.width * 0.5f;
+    g.half_h = (float)cfg.height * 0.5f;
+    return g;
+}
+
+struct HostMesh {
+    const sxe_vertex *v;
+    uint32_t nv;
+    const uint32_t *idx;
+    uint32_t ni;
+};
+
+struct HostObject {
+    uint32_t mesh;
+    int32_t texture;
+    uint32_t rendered;
+    sxe_transform transform;
+};
+
+// Shared tail of update_drawables / update_instances: pools the meshes, derives the draw list
+// (src/renderer/drawer.rs:173-214, 481-487, 313-347) and uploads everything.
+int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<HostObject> &ho)
+{
+    SXE_HIP(c, hipSetDevice(c->cfg.device));
+    // finish whatever still reads the old scene
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    c->frame_pending = false;
+
+    const bool need_tex = c->cfg.shading != SXE_SHADE_VERTEX_COLOR;
+    std::vector<MeshDev> meshes(hm.size());
+    size_t nv_total = 0, ni_total = 0;
+    for (size_t m = 0; m < hm.size(); ++m) {
+        if (hm[m].ni % 3) return fail(c, SXE_E_INVALID, "mesh %zu: index count %u is not a multiple of 3", m, hm[m].ni);
+        if ((hm[m].nv && !hm[m].v) || (hm[m].ni && !hm[m].idx)) return fail(c, SXE_E_INVALID, "mesh %zu: null data", m);
+        for (uint32_t k = 0; k < hm[m].ni; ++k)
+            if (hm[m].idx[k] >= hm[m].nv) return fail(c, SXE_E_INVALID, "mesh %zu: index %u out of range", m, hm[m].idx[k]);
+        meshes[m].vtx_base = (uint32_t)nv_total; // kept a multiple of 4 for 128-bit SoA loads
+        meshes[m].n_vtx = hm[m].nv;
+        meshes[m].idx_base = (uint32_t)ni_total;
+        meshes[m].n_tri = hm[m].ni / 3;
+        nv_total += (hm[m].nv + 3u) & ~3u;
+        ni_total += hm[m].ni;
+        if (nv_total > 0xFFFFFFF0ull || ni_total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "scene pools exceed 2^32 elements");
+    }
+    std::vector<sxe_vertex> verts(nv_total);
+    std::vector<float> px(nv_total), py(nv_total), pz(nv_total);
+    std::vector<uint32_t> idx(ni_total);
+    if (nv_total) memset(verts.data(), 0, nv_total * sizeof(sxe_vertex));
+    for (size_t m = 0; m < hm.size(); ++m) {
+        if (hm[m].nv) memcpy(&verts[meshes[m].vtx_base], hm[m].v, hm[m].nv * sizeof(sxe_vertex));
+        if (hm[m].ni) memcpy(&idx[meshes[m].idx_base], hm[m].idx, hm[m].ni * sizeof(uint32_t));
+    }
+    for (size_t v = 0; v < nv_total; ++v) {
+        px[v] = verts[v].pos[0];
+        py[v] = verts[v].pos[1];
+        pz[v] = verts[v].pos[2];
+    }
+
+    // draw order: texture groups ascending, caller order inside a group; unrendered meshes skipped
+    std::vector<uint32_t> order;
+    order.reserve(ho.size());
+    for (uint32_t o = 0; o < ho.size(); ++o) {
+        if (ho[o].mesh >= hm.size()) return fail(c, SXE_E_INVALID, "object %u: mesh %u out of range", o, ho[o].mesh);
+        if (!ho[o].rendered) continue;
+        if (need_tex && (ho[o].texture < 0 || (uint32_t)ho[o].texture >= c->n_textures))
+            return fail(c, SXE_E_INVALID, "object %u: texture %d is not in the texture table (%u entries)", o,
+                        ho[o].texture, c->n_textures);
+        order.push_back(o);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ho[a].texture < ho[b].texture; });
+
+    std::vector<InstDev> insts(order.size());
+    std::vector<BlockDesc> blocks;
+    uint64_t prims = 0;
+    for (size_t d = 0; d < order.size(); ++d) {
+        const HostObject &o = ho[order[d]];
+        insts[d].mesh = o.mesh;
+        insts[d].object = order[d];
+        insts[d].texture = o.texture;
+        insts[d].prim_base = (uint32_t)prims;
+        const uint32_t nt = meshes[o.mesh].n_tri;
+        for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) blocks.push_back({(uint32_t)d, t0});
+        prims += nt;
+        if (prims > SXE_MAX_PRIMS) return fail(c, SXE_E_CAPACITY, "more than %u triangles per frame", SXE_MAX_PRIMS);
+    }
+    // vertex-kernel work items and the clip-position layout: objects in caller order
+    std::vector<VBlockDesc> vblocks;
+    uint64_t inst_vtx = 0;
+    for (uint32_t o = 0; o < ho.size(); ++o) {
+        const uint32_t nv = meshes[ho[o].mesh].n_vtx;
+        for (uint32_t v0 = 0; v0 < nv; v0 += 1024) vblocks.push_back({o, v0, ho[o].mesh, (uint32_t)inst_vtx});
+        inst_vtx += nv;
+        if (inst_vtx > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "more than 2^32 instance vertices");
+    }
+
+    std::vector<float> models(16 * ho.size());
+    std::vector<sxe_transform> transforms(ho.size());
+    for (size_t o = 0; o < ho.size(); ++o) {
+        transforms[o] = ho[o].transform;
+        sxe_transform_to_model(&ho[o].transform, &models[16 * o]);
+    }
+
+    auto up = [&](auto &buf, const auto &vec) -> hipError_t {
+        hipError_t e = buf.reserve(std::max<size_t>(vec.size(), 1));
+        if (e != hipSuccess || vec.empty()) return e;
+        return hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice);
+    };
+    SXE_HIP(c, up(c->vertices, verts));
+    SXE_HIP(c, up(c->pos_x, px));
+    SXE_HIP(c, up(c->pos_y, py));
+    SXE_HIP(c, up(c->pos_z, pz));
+    SXE_HIP(c, up(c->indices, idx));
+    SXE_HIP(c, up(c->meshes, meshes));
+    SXE_HIP(c, up(c->insts, insts));
+    SXE_HIP(c, up(c->blocks, blocks));
+    SXE_HIP(c, up(c->vblocks, vblocks));
+    SXE_HIP(c, up(c->models, models));
+    SXE_HIP(c, up(c->transforms, transforms));
+    SXE_HIP(c, c->pvm.reserve(std::max<size_t>(models.size(), 16)));
+    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1)));
+    SXE_HIP(c, c->blk_base.reserve(std::max<size_t>(blocks.size(), 1)));
+
+    c->n_meshes = (uint32_t)hm.size();
+    c->n_objects = (uint32_t)ho.size();
+    c->n_draws = (uint32_t)insts.size();
+    c->n_blocks = (uint32_t)blocks.size();
+    c->n_vblocks = (uint32_t)vblocks.size();
+    c->n_prims = prims;
+    c->n_inst_vertices = inst_vtx;
+    c->have_transforms = true;
+    c->have_scene = true;
+
+    // first guess for the work buffers; sxe_sync grows them and redraws when a frame needs more
+    const size_t want_rec = std::max<size_t>(4096, (size_t)(prims / 2 + 1024));
+    const size_t want_bin = std::max<size_t>(4096, (size_t)(prims / 2 + 4 * (uint64_t)c->g.n_tiles));
+    if (want_rec > c->rec_capacity) {
+        SXE_HIP(c, c->rast.reserve(want_rec));
+        SXE_HIP(c, c->shade.reserve(want_rec));
+        if (c->cfg.shading != SXE_SHADE_TEXTURE) SXE_HIP(c, c->color.reserve(want_rec));
+        c->rec_capacity = want_rec;
+    }
+    if (want_bin > c->bin_capacity) {
+        SXE_HIP(c, c->bins.reserve(want_bin));
+        c->bin_capacity = want_bin;
+    }
+    return SXE_OK;
+}
+
+int enqueue_frame(sxe_ctx *c, uint32_t image_index)
+{
+    Image &img = c->images[image_index];
+    const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
+    hipStream_t s = c->stream;
+    const uint32_t nt = c->g.n_tiles;
+
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_BEGIN], s));
+    SXE_HIP(c, launch_object(c->models.p, c->pv, c->pvm.p, c->n_objects, s));
+    SXE_HIP(c, hipMemsetAsync(c->tile_counters.p, 0, 2 * (size_t)std::max<uint32_t>(nt, 1) * sizeof(uint32_t), s));
+    SXE_HIP(c, hipMemsetAsync(c->counters.p, 0, sizeof(FrameCounters), s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_OBJECT], s));
+
+    SetupArgs sa;
+    sa.vertices = c->vertices.p;
+    sa.indices = c->indices.p;
+    sa.meshes = c->meshes.p;
+    sa.insts = c->insts.p;
+    sa.blocks = c->blocks.p;
+    sa.pvm = c->pvm.p;
+    sa.n_blocks = c->n_blocks;
+    sa.shading = c->cfg.shading;
+    sa.g = c->g;
+    sa.blk_count = c->blk_count.p;
+    sa.blk_base = c->blk_base.p;
+    sa.tile_count = c->tile_counters.p;
+    sa.tile_off = c->tile_off.p;
+    sa.tile_fill = c->tile_counters.p + std::max<uint32_t>(nt, 1);
+    sa.rast = c->rast.p;
+    sa.shade = c->shade.p;
+    sa.color = c->color.p;
+    sa.bins = c->bins.p;
+    sa.counters = c->counters.p;
+    SXE_HIP(c, launch_setup_count(sa, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_COUNT], s));
+
+    ScanArgs sc;
+    sc.blk_count = c->blk_count.p;
+    sc.blk_base = c->blk_base.p;
+    sc.n_blocks = c->n_blocks;
+    sc.tile_count = sa.tile_count;
+    sc.tile_off = c->tile_off.p;
+    sc.n_tiles = nt;
+    sc.rec_capacity = (uint32_t)std::min<size_t>(c->rec_capacity, 0xFFFFFFFFu);
+    sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
+    sc.counters = c->counters.p;
+    SXE_HIP(c, launch_scan(sc, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_SCAN], s));
+
+    SXE_HIP(c, launch_setup_emit(sa, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_EMIT], s));
+
+    RasterArgs ra;
+    ra.g = c->g;
+    ra.tile_count = sa.tile_count;
+    ra.tile_off = c->tile_off.p;
+    ra.bins = c->bins.p;
+    ra.rast = c->rast.p;
+    ra.shade = c->shade.p;
+    ra.color = c->color.p;
+    ra.counters = c->counters.p;
+    ra.texels = c->texels.p;
+    ra.textures = c->textab.p;
+    ra.out_color = img.color.p;
+    ra.out_depth = img.depth.p;
+    ra.out_prim = (c->cfg.flags & SXE_FLAG_WRITE_COVERAGE) ? img.prim.p : nullptr;
+    ra.clear_code = srgb_encode_host(c->cfg.clear[0]) | (srgb_encode_host(c->cfg.clear[1]) << 8) |
+                    (srgb_encode_host(c->cfg.clear[2]) << 16) | (unorm8_host(c->cfg.clear[3]) << 24);
+    ra.shading = c->cfg.shading;
+    SXE_HIP(c, launch_raster_shade(ra, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_RASTER], s));
+
+    SXE_HIP(c, hipMemcpyAsync(c->h_counters, c->counters.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+    img.drawn = true;
+    c->last_image = (int)image_index;
+    c->frame_pending = true;
+    return SXE_OK;
+}
+
+int check_ctx(sxe_ctx *c)
+{
+    if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
+    hipError_t e = hipSetDevice(c->cfg.device);
+    if (e != hipSuccess) return fail(c, SXE_E_DEVICE, "hipSetDevice(%d) failed: %s", c->cfg.device, hipGetErrorString(e));
+    return SXE_OK;
+}
+
+int read_image_plane(sxe_ctx *c, uint32_t image_index, void *dst, size_t size_bytes, int plane)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
+    Image &img = c->images[image_index];
+    if (!img.drawn) return fail(c, SXE_E_STATE, "image %u was never drawn", image_index);
+    const size_t px = (size_t)c->cfg.width * c->cfg.height;
+    const size_t need = px * 4;
+    if (!dst || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    rc = sxe_sync(c);
+    if (rc) return rc;
+    const void *src = plane == 0 ? (const void *)img.color.p : plane == 1 ? (const void *)img.depth.p : (const void *)img.prim.p;
+    if (!src) return fail(c, SXE_E_STATE, "coverage was not requested (SXE_FLAG_WRITE_COVERAGE)");
+    // rows outside the scissor were never written: report them as cleared
+    SXE_HIP(c, hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    return SXE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *sxe_version(void) { return "sxe-hip 0.1 (gfx950)"; }
+
+void sxe_default_config(sxe_config *cfg, uint32_t width, uint32_t height)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->width = width;
+    cfg->height = height;
+    cfg->fov_deg = 45.0f;  // src/renderer/drawer.rs:249
+    cfg->z_near = 0.1f;    // :251
+    cfg->z_far = 1000.0f;  // :252
+    cfg->clear[0] = 0.7f;  // :307
+    cfg->clear[1] = 0.2f;
+    cfg->clear[2] = 0.0f;
+    cfg->clear[3] = 1.0f;
+    cfg->device = 0;
+    cfg->n_images = 2;
+    cfg->scissor_y0 = 0;
+    cfg->scissor_y1 = 0;
+    cfg->shading = SXE_SHADE_TEXTURE;
+    cfg->flags = 0;
+}
+
+const char *sxe_last_error(const sxe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sxe_create(const sxe_config *cfg, sxe_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, SXE_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->width == 0 || cfg->height == 0 || cfg->width > SXE_MAX_DIM || cfg->height > SXE_MAX_DIM)
+        return fail(nullptr, SXE_E_INVALID, "frame size %ux%u outside 1..%u", cfg->width, cfg->height, SXE_MAX_DIM);
+    if (cfg->shading > SXE_SHADE_COLOR_TIMES_TEXTURE) return fail(nullptr, SXE_E_INVALID, "unknown shading mode %u", cfg->shading);
+    if (!(cfg->fov_deg > 0.0f && cfg->fov_deg < 180.0f) || !(cfg->z_near > 0.0f) || !(cfg->z_far > cfg->z_near))
+        return fail(nullptr, SXE_E_INVALID, "bad perspective parameters");
+    sxe_config k = *cfg;
+    if (k.scissor_y0 == 0 && k.scissor_y1 == 0) k.scissor_y1 = k.height;
+    if (k.scissor_y0 > k.scissor_y1 || k.scissor_y1 > k.height)
+        return fail(nullptr, SXE_E_INVALID, "scissor rows [%u,%u) outside the frame", k.scissor_y0, k.scissor_y1);
+    if (k.n_images == 0) k.n_images = 1;
+    if (k.n_images > 16) return fail(nullptr, SXE_E_CAPACITY, "at most 16 images");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SXE_E_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (k.device < 0 || k.device >= ndev) return fail(nullptr, SXE_E_INVALID, "device %d not in 0..%d", k.device, ndev - 1);
+    e = hipSetDevice(k.device);
+    if (e != hipSuccess) return fail(nullptr, SXE_E_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
+
+    sxe_ctx *c = new (std::nothrow) sxe_ctx();
+    if (!c) return fail(nullptr, SXE_E_DEVICE, "out of host memory");
+    c->cfg = k;
+    c->g = make_geom(k);
+    c->view = identity();
+    c->proj = identity();
+    c->pv = identity();
+    auto bail = [&](const char *what, hipError_t err) {
+        fail(nullptr, SXE_E_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
+        sxe_destroy(c);
+        return SXE_E_DEVICE;
+    };
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int i = 0; i < EV_N; ++i)
+        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+    for (int i = 0; i < 2; ++i)
+        if ((e = hipEventCreate(&c->ev_tr[i])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(FrameCounters), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+    memset(c->h_counters, 0, sizeof(FrameCounters));
+    const size_t px = (size_t)k.width * k.height;
+    c->images.resize(k.n_images);
+    for (auto &img : c->images) {
+        if ((e = img.color.reserve(px * 4)) != hipSuccess) return bail("hipMalloc(color)", e);
+        if ((e = img.depth.reserve(px)) != hipSuccess) return bail("hipMalloc(depth)", e);
+        if (k.flags & SXE_FLAG_WRITE_COVERAGE)
+            if ((e = img.prim.reserve(px)) != hipSuccess) return bail("hipMalloc(coverage)", e);
+        // rows outside the scissor are never written by a frame: start them cleared
+        if ((e = hipMemset(img.color.p, 0, px * 4)) != hipSuccess) return bail("hipMemset", e);
+        if ((e = hipMemset(img.depth.p, 0, px * 4)) != hipSuccess) return bail("hipMemset", e);
+        if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
+    }
+    const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
+    if ((e = c->tile_counters.reserve(2 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_off.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile offsets)", e);
+    if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
+    if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
+    if ((e = c->textab.reserve(1)) != hipSuccess) return bail("hipMalloc(texture table)", e);
+    *out = c;
+    return SXE_OK;
+}
+
+void sxe_destroy(sxe_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
+    c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
+    c->models.release(); c->pvm.release(); c->transforms.release(); c->texels.release(); c->textab.release();
+    c->blk_count.release(); c->blk_base.release(); c->tile_counters.release(); c->tile_off.release();
+    c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
+    c->clip.release();
+    for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (int i = 0; i < EV_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i) if (c->ev_tr[i]) (void)hipEventDestroy(c->ev_tr[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (n && !textures) return fail(c, SXE_E_INVALID, "null texture table");
+    if (n > 65536) return fail(c, SXE_E_CAPACITY, "at most 65536 textures");
+    std::vector<TexDev> tab(n);
+    size_t total = 0;
+    for (uint32_t t = 0; t < n; ++t) {
+        const sxe_texture_desc &d = textures[t];
+        if (!d.rgba || d.width == 0 || d.height == 0 || d.width > 16384 || d.height > 16384)
+            return fail(c, SXE_E_INVALID, "texture %u: bad size %ux%u or null pixels", t, d.width, d.height);
+        const size_t px = (size_t)d.width * d.height;
+        for (size_t i = 0; i < px; ++i)
+            if (d.rgba[4 * i + 3] != 255)
+                return fail(c, SXE_E_INVALID,
+                            "texture %u is not opaque (pixel %zu has alpha %u): blending is resolved once per pixel, "
+                            "which equals the reference's in-order blending only for opaque texels",
+                            t, i, d.rgba[4 * i + 3]);
+        tab[t].offset = (uint32_t)total;
+        tab[t].width = d.width;
+        tab[t].height = d.height;
+        tab[t].pad = 0;
+        total += px;
+        if (total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
+    }
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16)));
+    SXE_HIP(c, c->textab.reserve(std::max<size_t>(n, 1)));
+    for (uint32_t t = 0; t < n; ++t)
+        SXE_HIP(c, hipMemcpy(c->texels.p + 4 * (size_t)tab[t].offset, textures[t].rgba,
+                             4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice));
+    if (n) SXE_HIP(c, hipMemcpy(c->textab.p, tab.data(), n * sizeof(TexDev), hipMemcpyHostToDevice));
+    c->n_textures = n;
+    return SXE_OK;
+}
+
+int sxe_update_drawables(sxe_ctx *c, const sxe_drawable *drawables, uint32_t n)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (n && !drawables) return fail(c, SXE_E_INVALID, "null drawable array");
+    std::vector<HostMesh> hm(n);
+    std::vector<HostObject> ho(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        hm[i] = {drawables[i].vertices, drawables[i].n_vertices, drawables[i].indices, drawables[i].n_indices};
+        ho[i] = {i, drawables[i].texture, drawables[i].rendered, drawables[i].transform};
+    }
+    return upload_scene(c, hm, ho);
+}
+
+int sxe_update_instances(sxe_ctx *c, const sxe_mesh_desc *meshes, uint32_t n_meshes, const sxe_instance *instances,
+                         uint32_t n_instances)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if ((n_meshes && !meshes) || (n_instances && !instances)) return fail(c, SXE_E_INVALID, "null array");
+    std::vector<HostMesh> hm(n_meshes);
+    std::vector<HostObject> ho(n_instances);
+    for (uint32_t i = 0; i < n_meshes; ++i) hm[i] = {meshes[i].vertices, meshes[i].n_vertices, meshes[i].indices, meshes[i].n_indices};
+    for (uint32_t i = 0; i < n_instances; ++i)
+        ho[i] = {instances[i].mesh, instances[i].texture, instances[i].rendered, instances[i].transform};
+    return upload_scene(c, hm, ho);
+}
+
+int sxe_update_uniforms(sxe_ctx *c, const float *models, uint32_t n)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "update_uniforms before update_drawables");
+    if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u model matrices for %u objects", n, c->n_objects);
+    if (n && !models) return fail(c, SXE_E_INVALID, "null matrices");
+    if (n) SXE_HIP(c, hipMemcpyAsync(c->models.p, models, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+    // the caller's buffer is only borrowed for the call
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_transforms = false;
+    return SXE_OK;
+}
+
+int sxe_update_transforms(sxe_ctx *c, const sxe_transform *transforms, uint32_t n)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "update_transforms before update_drawables");
+    if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u transforms for %u objects", n, c->n_objects);
+    if (n && !transforms) return fail(c, SXE_E_INVALID, "null transforms");
+    if (n) {
+        SXE_HIP(c, hipMemcpyAsync(c->transforms.p, transforms, (size_t)n * sizeof(sxe_transform), hipMemcpyHostToDevice, c->stream));
+        SXE_HIP(c, launch_transform_to_model(c->transforms.p, c->models.p, n, c->stream));
+        SXE_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_transforms = (n == c->n_objects) || c->have_transforms;
+    return SXE_OK;
+}
+
+int sxe_rotation_system(sxe_ctx *c, uint64_t seed, uint32_t frame, float delta_ms)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "rotation_system before update_drawables");
+    if (!c->have_transforms) return fail(c, SXE_E_STATE, "model matrices were set directly; no transforms to rotate");
+    const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev_tr[0], c->stream));
+    SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, delta_ms, c->stream));
+    if (timing) {
+        SXE_HIP(c, hipEventRecord(c->ev_tr[1], c->stream));
+        c->transform_timed = true;
+    }
+    return SXE_OK;
+}
+
+int sxe_update_camera_matrices(sxe_ctx *c, const float *view, const float *proj)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!view || !proj) return fail(c, SXE_E_INVALID, "null matrix");
+    memcpy(c->view.m, view, 64);
+    memcpy(c->proj.m, proj, 64);
+    c->pv = mul(c->proj, c->view); // standard.vert:28: proj * view (* model per object, on the device)
+    c->have_camera = true;
+    return SXE_OK;
+}
+
+int sxe_update_camera(sxe_ctx *c, const sxe_transform *camera)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!camera) return fail(c, SXE_E_INVALID, "null camera transform");
+    float view[16], proj[16];
+    // the reference derives the aspect from DIMS (src/renderer/drawer.rs:508); this build uses the target
+    const float aspect = (float)c->cfg.width / (float)c->cfg.height;
+    sxe_camera_matrices(camera, c->cfg.fov_deg, aspect, c->cfg.z_near, c->cfg.z_far, view, proj);
+    return sxe_update_camera_matrices(c, view, proj);
+}
+
+int sxe_draw(sxe_ctx *c, uint32_t image_index)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "draw before update_drawables");
+    if (!c->have_camera) return fail(c, SXE_E_STATE, "draw before update_camera");
+    if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
+    if (c->frame_pending) {
+        // a previous frame may still need its work buffers grown: settle it first
+        rc = sxe_sync(c);
+        if (rc) return rc;
+    }
+    return enqueue_frame(c, image_index);
+}
+
+int sxe_sync(sxe_ctx *c)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->frame_pending) return SXE_OK;
+    for (int attempt = 0; attempt < 4 && c->h_counters->overflow; ++attempt) {
+        // a work buffer was too small: grow to what the frame asked for and render it again
+        const size_t need_rec = (size_t)c->h_counters->total_records + (size_t)c->h_counters->total_records / 4 + 1024;
+        const size_t need_bin = (size_t)c->h_counters->total_pairs + (size_t)c->h_counters->total_pairs / 4 + 1024;
+        if (need_rec > c->rec_capacity) {
+            SXE_HIP(c, c->rast.reserve(need_rec));
+            SXE_HIP(c, c->shade.reserve(need_rec));
+            if (c->cfg.shading != SXE_SHADE_TEXTURE) SXE_HIP(c, c->color.reserve(need_rec));
+            c->rec_capacity = need_rec;
+        }
+        if (need_bin > c->bin_capacity) {
+            SXE_HIP(c, c->bins.reserve(need_bin));
+            c->bin_capacity = need_bin;
+        }
+        c->redraws++;
+        rc = enqueue_frame(c, (uint32_t)c->last_image);
+        if (rc) return rc;
+        SXE_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->frame_pending = false;
+    if (c->h_counters->overflow) return fail(c, SXE_E_CAPACITY, "frame still overflows its work buffers after regrowth");
+    c->stats.prims = c->n_prims;
+    c->stats.records = c->h_counters->total_records;
+    c->stats.bin_entries = c->h_counters->total_pairs;
+    c->stats.tiles = c->g.n_tiles;
+    c->stats.instance_vertices = c->n_inst_vertices;
+    c->stats.objects = c->n_objects;
+    c->stats.tile_size = kTile;
+    c->stats.redraws = c->redraws;
+    if (c->cfg.flags & SXE_FLAG_TIMING) {
+        float ms[EV_N] = {};
+        for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i - 1], c->ev[i]));
+        c->timings.object_ms = ms[EV_OBJECT];
+        c->timings.setup_count_ms = ms[EV_COUNT];
+        c->timings.scan_ms = ms[EV_SCAN];
+        c->timings.setup_emit_ms = ms[EV_EMIT];
+        c->timings.raster_shade_ms = ms[EV_RASTER];
+        SXE_HIP(c, hipEventElapsedTime(&c->timings.frame_ms, c->ev[EV_BEGIN], c->ev[EV_RASTER]));
+        c->timings.transform_ms = 0.0f;
+        if (c->transform_timed) SXE_HIP(c, hipEventElapsedTime(&c->timings.transform_ms, c->ev_tr[0], c->ev_tr[1]));
+    }
+    return SXE_OK;
+}
+
+int sxe_read_color(sxe_ctx *c, uint32_t image_index, uint8_t *rgba, size_t size_bytes)
+{
+    return read_image_plane(c, image_index, rgba, size_bytes, 0);
+}
+
+int sxe_read_depth(sxe_ctx *c, uint32_t image_index, float *depth, size_t size_bytes)
+{
+    return read_image_plane(c, image_index, depth, size_bytes, 1);
+}
+
+int sxe_read_coverage(sxe_ctx *c, uint32_t image_index, uint32_t *prim_ids, size_t size_bytes)
+{
+    return read_image_plane(c, image_index, prim_ids, size_bytes, 2);
+}
+
+int sxe_read_clip_positions(sxe_ctx *c, float *clip, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene || !c->have_camera) return fail(c, SXE_E_STATE, "read_clip_positions needs a scene and a camera");
+    const size_t need = (size_t)c->n_inst_vertices * 16;
+    if (!clip || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    SXE_HIP(c, c->clip.reserve(std::max<size_t>(c->n_inst_vertices, 1)));
+    SXE_HIP(c, launch_object(c->models.p, c->pv, c->pvm.p, c->n_objects, c->stream));
+    SXE_HIP(c, launch_vertex(c->pos_x.p, c->pos_y.p, c->pos_z.p, c->meshes.p, c->vblocks.p, c->n_vblocks, c->pvm.p,
+                             c->clip.p, c->stream));
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    if (need) SXE_HIP(c, hipMemcpy(clip, c->clip.p, need, hipMemcpyDeviceToHost));
+    return SXE_OK;
+}
+
+int sxe_read_models(sxe_ctx *c, float *models, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "no scene");
+    const size_t need = (size_t)c->n_objects * 64;
+    if (!models || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    if (need) SXE_HIP(c, hipMemcpy(models, c->models.p, need, hipMemcpyDeviceToHost));
+    return SXE_OK;
+}
+
+int sxe_read_transforms(sxe_ctx *c, sxe_transform *transforms, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene || !c->have_transforms) return fail(c, SXE_E_STATE, "no device-resident transforms");
+    const size_t need = (size_t)c->n_objects * sizeof(sxe_transform);
+    if (!transforms || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    if (need) SXE_HIP(c, hipMemcpy(transforms, c->transforms.p, need, hipMemcpyDeviceToHost));
+    return SXE_OK;
+}
+
+int sxe_color_device_ptr(sxe_ctx *c, uint32_t image_index, void **ptr)
+{
+    if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
+    if (!ptr || image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "bad image index or null pointer");
+    *ptr = c->images[image_index].color.p;
+    return SXE_OK;
+}
+
+int sxe_get_timings(sxe_ctx *c, sxe_timings *out)
+{
+    if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
+    if (!out) return fail(c, SXE_E_INVALID, "null output");
+    if (!(c->cfg.flags & SXE_FLAG_TIMING)) return fail(c, SXE_E_STATE, "context was created without SXE_FLAG_TIMING");
+    *out = c->timings;
+    return SXE_OK;
+}
+
+int sxe_get_stats(sxe_ctx *c, sxe_frame_stats *out)
+{
+    if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
+    if (!out) return fail(c, SXE_E_INVALID, "null output");
+    *out = c->stats;
+    return SXE_OK;
+}
+
+// ---- host-side Transform / camera maths ----
+
+void sxe_transform_identity(sxe_transform *t)
+{
+    const Quat q = quat_from_euler_deg(0.0f, 0.0f, 0.0f);
+    t->position[0] = t->position[1] = t->position[2] = 0.0f;
+    t->scale[0] = t->scale[1] = t->scale[2] = 1.0f;
+    t->rotation[0] = q.s; t->rotation[1] = q.x; t->rotation[2] = q.y; t->rotation[3] = q.z;
+}
+
+void sxe_transform_translate(sxe_transform *t, float x, float y, float z)
+{
+    t->position[0] = t->position[0] + x;
+    t->position[1] = t->position[1] + y;
+    t->position[2] = t->position[2] + z;
+}
+
+void sxe_transform_rotate(sxe_transform *t, float x, float y, float z)
+{
+    const Quat by = quat_from_euler_deg(x, y, z);
+    const Quat q0 = {t->rotation[0], t->rotation[1], t->rotation[2], t->rotation[3]};
+    const Quat q = mul(q0, by);
+    t->rotation[0] = q.s; t->rotation[1] = q.x; t->rotation[2] = q.y; t->rotation[3] = q.z;
+}
+
+void sxe_transform_to_model(const sxe_transform *t, float model[16])
+{
+    const Quat q = {t->rotation[0], t->rotation[1], t->rotation[2], t->rotation[3]};
+    const Mat4 M = model_matrix(t->position, t->scale, q);
+    memcpy(model, M.m, 64);
+}
+
+void sxe_camera_matrices(const sxe_transform *camera, float fov_deg, float aspect, float z_near, float z_far,
+                         float view[16], float proj[16])
+{
+    const Quat q = {camera->rotation[0], camera->rotation[1], camera->rotation[2], camera->rotation[3]};
+    float ex, ey, ez;
+    euler_from_quat(q, ex, ey, ez);
+    (void)ez; // roll is ignored by the reference
+    // argument order of src/renderer/drawer.rs:246: pitch = euler.y, yaw = euler.x
+    const Mat4 V = fps_view(camera->position, ey, ex);
+    const Mat4 P = perspective_yflip(fov_deg, aspect, z_near, z_far);
+    memcpy(view, V.m, 64);
+    memcpy(proj, P.m, 64);
+}
+
+} // extern "C"

@@ -1,0 +1,206 @@
+"""Deterministic synthetic scenes for the raster/shade path (inputs only: no rendering here).
+
+The reference ships one concrete mesh, `Cube::new` (src/primitives/three_d/cube.rs:12-83), builds
+its world from 64 randomly placed cubes (src/main.rs:201-227) and cannot hold more than 1024
+objects (src/renderer/allocator.rs:311-318); its textures are git-LFS pointers.  The benchmark
+configurations therefore use the cube, a 1,024-triangle grid sphere, and procedural opaque RGBA8
+textures, all generated from fixed seeds.
+"""
+import numpy as np
+
+from . import api
+from .api import MESH, OBJECT, TRANSFORM, VERTEX
+
+
+class Scene:
+    def __init__(self, vertices, indices, meshes, objects, transforms, textures, camera=None, size=(800, 600),
+                 name="scene"):
+        self.vertices = np.ascontiguousarray(vertices, dtype=VERTEX)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        self.meshes = np.ascontiguousarray(meshes, dtype=MESH)
+        self.objects = np.ascontiguousarray(objects, dtype=OBJECT)
+        self.transforms = np.ascontiguousarray(transforms, dtype=TRANSFORM)
+        self.textures = [np.ascontiguousarray(t, dtype=np.uint8) for t in textures]
+        self.camera = api.identity_transforms(1) if camera is None else np.ascontiguousarray(camera, dtype=TRANSFORM).reshape(1)
+        self.size = size
+        self.name = name
+
+    @property
+    def n_triangles(self):
+        o = self.objects
+        return int((self.meshes["n_indices"][o["mesh"]][o["rendered"] != 0] // 3).sum())
+
+    def drawables(self):
+        """The same scene as a list of reference-style drawables (one mesh copy per object)."""
+        out = []
+        for o, t in zip(self.objects, self.transforms):
+            m = self.meshes[o["mesh"]]
+            v = self.vertices[m["first_vertex"]:m["first_vertex"] + m["n_vertices"]]
+            i = self.indices[m["first_index"]:m["first_index"] + m["n_indices"]]
+            out.append(api.Drawable(v, i, t, int(o["texture"]), bool(o["rendered"])))
+        return out
+
+
+def cube_mesh():
+    """Cube::new: 24 vertices, 36 indices, +-0.5, per-face colour and uv (cube.rs:28-73)."""
+    lo, hi = -0.5, 0.5
+    red, green, blue = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    yellow, purple, blue_green = (1, 1, 0), (1, 0, 1), (0, 1, 1)
+    uv = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    faces = [
+        (red, [(lo, lo, lo), (lo, hi, lo), (hi, hi, lo), (hi, lo, lo)]),          # back
+        (green, [(lo, lo, hi), (hi, lo, hi), (hi, hi, hi), (lo, hi, hi)]),        # front
+        (blue, [(lo, lo, hi), (lo, hi, hi), (lo, hi, lo), (lo, lo, lo)]),         # left
+        (yellow, [(hi, lo, hi), (hi, lo, lo), (hi, hi, lo), (hi, hi, hi)]),       # right
+        (purple, [(lo, hi, hi), (hi, hi, hi), (hi, hi, lo), (lo, hi, lo)]),       # top
+        (blue_green, [(lo, lo, hi), (lo, lo, lo), (hi, lo, lo), (hi, lo, hi)]),   # bottom
+    ]
+    v = np.zeros(24, dtype=VERTEX)
+    k = 0
+    for colour, corners in faces:
+        for c, t in zip(corners, uv):
+            v[k]["pos"], v[k]["color"], v[k]["uv"] = c, colour, t
+            k += 1
+    idx = []
+    for f in range(6):
+        b = 4 * f
+        idx += [b, b + 1, b + 2, b + 2, b + 3, b]
+    return v, np.array(idx, dtype=np.uint32)
+
+
+def grid_sphere_mesh(n_lon=32, n_lat=16, radius=0.5):
+    """(n_lon+1) x (n_lat+1) grid wrapped on a sphere: 561 vertices / 1,024 triangles by default.
+    Pole cells contain zero-area triangles on purpose (the setup stage must cull them)."""
+    i = np.arange(n_lon + 1)
+    j = np.arange(n_lat + 1)
+    ii, jj = np.meshgrid(i, j, indexing="xy")
+    theta = 2.0 * np.pi * ii / n_lon
+    phi = np.pi * jj / n_lat
+    v = np.zeros((n_lat + 1) * (n_lon + 1), dtype=VERTEX)
+    v["pos"][:, 0] = (radius * np.sin(phi) * np.cos(theta)).ravel()
+    v["pos"][:, 1] = (radius * np.cos(phi)).ravel()
+    v["pos"][:, 2] = (radius * np.sin(phi) * np.sin(theta)).ravel()
+    v["uv"][:, 0] = (ii / n_lon).ravel()
+    v["uv"][:, 1] = (jj / n_lat).ravel()
+    h = (ii * 73856093 ^ jj * 19349663).ravel().astype(np.uint64)
+    v["color"][:, 0] = ((h >> 0) & 255) / 255.0
+    v["color"][:, 1] = ((h >> 8) & 255) / 255.0
+    v["color"][:, 2] = ((h >> 16) & 255) / 255.0
+    idx = []
+    w = n_lon + 1
+    for y in range(n_lat):
+        for x in range(n_lon):
+            a, b, c, d = y * w + x, y * w + x + 1, (y + 1) * w + x + 1, (y + 1) * w + x
+            idx += [a, b, c, c, d, a]
+    return v, np.array(idx, dtype=np.uint32)
+
+
+def checker_texture(size, seed):
+    """Opaque RGBA8 (sRGB-encoded) checker of 8x8-texel blocks in two seeded colours with a
+    gradient across u and v."""
+    rng = np.random.default_rng(seed)
+    ca = rng.integers(64, 256, size=3)
+    cb = rng.integers(0, 160, size=3)
+    y, x = np.mgrid[0:size, 0:size]
+    chk = ((x // 8 + y // 8) & 1).astype(bool)
+    t = np.zeros((size, size, 4), dtype=np.uint8)
+    gx = 96 + (x * 159) // max(size - 1, 1)
+    gy = 96 + (y * 159) // max(size - 1, 1)
+    for k in range(3):
+        g = gx if k != 1 else gy
+        t[..., k] = np.where(chk, (ca[k] * g) // 255, (cb[k] * g) // 255)
+    t[..., 3] = 255
+    return t
+
+
+def _single_mesh_scene(v, idx, transforms, textures_of, textures, **kw):
+    meshes = np.array([(0, len(v), 0, len(idx))], dtype=MESH)
+    objects = np.zeros(len(transforms), dtype=OBJECT)
+    objects["mesh"] = 0
+    objects["texture"] = textures_of
+    objects["rendered"] = 1
+    return Scene(v, idx, meshes, objects, transforms, textures, **kw)
+
+
+def cube_scene(width=800, height=600):
+    """Config 1: one textured cube at (0,0,-3) rotated by rotate(30,45,0); identity camera."""
+    v, idx = cube_mesh()
+    t = api.identity_transforms(1)
+    api.translate(t, 0, 0.0, 0.0, -3.0)
+    api.rotate(t, 0, 30.0, 45.0, 0.0)
+    return _single_mesh_scene(v, idx, t, 0, [checker_texture(256, 1)], size=(width, height), name="cfg1-cube")
+
+
+def reference_demo_scene(n=64, seed=7, width=1024, height=768):
+    """The world `start_engine` builds (src/main.rs:152-163,201-227): n cubes uniformly in
+    [-15,15]^3 with one of three textures, seen by an identity camera; seeded instead of thread_rng."""
+    v, idx = cube_mesh()
+    rng = np.random.default_rng(seed)
+    t = api.identity_transforms(n)
+    pos = rng.uniform(-15.0, 15.0, size=(n, 3)).astype(np.float32)
+    for i in range(n):
+        api.translate(t, i, float(pos[i, 0]), float(pos[i, 1]), float(pos[i, 2]))
+    tex = rng.integers(0, 3, size=n)
+    return _single_mesh_scene(v, idx, t, tex, [checker_texture(256, 10 + k) for k in range(3)],
+                              size=(width, height), name="reference-demo")
+
+
+def sphere_field_scene(n, seed, box_xy, z_range, width, height, n_textures=4, tex_size=512, name="spheres"):
+    """n instances of the 1,024-triangle grid sphere, uniformly placed in
+    [-box_xy,box_xy]^2 x [z_range], uniform scale in [0.5,1.5], random Euler rotation."""
+    v, idx = grid_sphere_mesh()
+    rng = np.random.default_rng(seed)
+    t = api.identity_transforms(1).repeat(n)
+    pos = np.empty((n, 3), dtype=np.float32)
+    pos[:, 0:2] = rng.uniform(-box_xy, box_xy, size=(n, 2))
+    pos[:, 2] = rng.uniform(z_range[0], z_range[1], size=n)
+    scale = rng.uniform(0.5, 1.5, size=n).astype(np.float32)
+    euler = rng.uniform(0.0, 360.0, size=(n, 3)).astype(np.float32)
+    t["position"] = pos
+    t["scale"] = scale[:, None]
+    t = np.ascontiguousarray(t)
+    for i in range(n):
+        api.rotate(t, i, float(euler[i, 0]), float(euler[i, 1]), float(euler[i, 2]))
+    tex = rng.integers(0, n_textures, size=n)
+    return _single_mesh_scene(v, idx, t, tex, [checker_texture(tex_size, 100 + k) for k in range(n_textures)],
+                              size=(width, height), name=name)
+
+
+def config_scene(cfg, scale=1.0):
+    """The benchmark configurations. `scale` < 1 shrinks object count and frame size together
+    for parity tests the CPU oracle can finish in seconds."""
+    if cfg == 1:
+        return cube_scene(max(8, int(800 * scale)), max(8, int(600 * scale)))
+    if cfg == 2:
+        return sphere_field_scene(max(1, int(100 * scale)), 2, 15.0, (-40.0, -5.0), max(8, int(1920 * scale)),
+                                  max(8, int(1080 * scale)), name="cfg2-100-spheres-1080p")
+    if cfg in (3, 4):
+        w, h = (3840, 2160) if cfg == 3 else (7680, 4320)
+        return sphere_field_scene(max(1, int(10000 * scale)), 3, 60.0, (-200.0, -5.0), max(8, int(w * scale)),
+                                  max(8, int(h * scale)), name="cfg%d-10k-spheres" % cfg)
+    if cfg == 5:
+        s = sphere_field_scene(max(1, int(100 * scale)), 2, 15.0, (-40.0, -5.0), max(8, int(512 * scale)),
+                               max(8, int(512 * scale)), name="cfg5-multiview")
+        return s
+    raise ValueError("unknown config %r" % (cfg,))
+
+
+def orbit_cameras(n, seed, radius=60.0, target=(0.0, 0.0, -22.5)):
+    """n camera Transforms on a seeded sphere looking at `target`, expressed so that
+    update_camera (euler.y -> pitch, euler.x -> yaw, src/renderer/drawer.rs:244-246) reproduces them."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:, 1] = np.clip(d[:, 1], -0.95, 0.95)  # keep |pitch| away from the gimbal branch
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    cams = api.identity_transforms(1).repeat(n)
+    cams = np.ascontiguousarray(cams)
+    tgt = np.asarray(target, dtype=np.float64)
+    for i in range(n):
+        eye = tgt + radius * d[i]
+        b = d[i]  # camera backward axis
+        pitch = -np.degrees(np.arcsin(b[1]))
+        yaw = np.degrees(np.arctan2(b[0], b[2]))
+        cams[i]["position"] = eye.astype(np.float32)
+        api.rotate(cams, i, float(yaw), float(pitch), 0.0)
+    return cams
