@@ -1,0 +1,93 @@
+"""Work split across GPUs: sort-first screen bands and frame-parallel views, plus the band gather.
+
+Nothing in the reference is distributed (one queue, one submission per frame,
+src/renderer/drawer.rs:426-454).  The split follows the two ways its frame decomposes:
+
+* sort-first: the framebuffer is cut into horizontal bands of whole tile rows, one band per rank;
+  geometry is replicated, bands are pixel-disjoint, so the only exchange is the final gather of
+  the finished RGBA8 rows (RCCL over xGMI when the backend is "nccl", gloo on CPU);
+* frame-parallel: independent views are dealt to ranks in contiguous blocks; no exchange at all.
+"""
+import numpy as np
+
+TILE = 32
+
+
+def band_rows(height, world, rank, tile=TILE):
+    """Rows [y0, y1) of rank's band: contiguous, whole tile rows, sizes differing by at most one tile row."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank %r of %r" % (rank, world))
+    n_tile_rows = (height + tile - 1) // tile
+    base, extra = divmod(n_tile_rows, world)
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    y0 = min(first * tile, height)
+    y1 = min((first + count) * tile, height)
+    return y0, y1
+
+
+def all_bands(height, world, tile=TILE):
+    return [band_rows(height, world, r, tile) for r in range(world)]
+
+
+def views_for_rank(n_views, world, rank):
+    """Contiguous block [v0, v1) of the views rendered by this rank."""
+    base, extra = divmod(n_views, world)
+    v0 = rank * base + min(rank, extra)
+    return v0, v0 + base + (1 if rank < extra else 0)
+
+
+def gather_bands(band, height, width, world, rank, dst=0, group=None):
+    """Collect every rank's finished band on rank `dst`.
+
+    `band` is this rank's rows as a (rows, width, 4) uint8 torch tensor (a CUDA tensor for the
+    nccl/RCCL backend, a CPU tensor for gloo).  Bands are padded to the tallest band so that one
+    equal-sized gather moves everything; returns the (height, width, 4) frame on `dst`, else None.
+    """
+    import torch
+    import torch.distributed as dist
+
+    bands = all_bands(height, world)
+    max_rows = max(y1 - y0 for y0, y1 in bands)
+    y0, y1 = bands[rank]
+    if tuple(band.shape) != (y1 - y0, width, 4) or band.dtype != torch.uint8:
+        raise ValueError("band has shape %s, expected %s uint8" % (tuple(band.shape), (y1 - y0, width, 4)))
+    send = band
+    if y1 - y0 != max_rows:
+        send = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=band.device)
+        send[: y1 - y0] = band
+    send = send.contiguous()
+    if world == 1:
+        return send[: y1 - y0]
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    frame = torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
+    for r, (a, b) in enumerate(bands):
+        frame[a:b] = recv[r][: b - a]
+    return frame
+
+
+class _DevicePtr:
+    """Zero-copy view of device memory for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr="|u1"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def band_tensor(drawer, image_index, y0, y1):
+    """The rows [y0,y1) of a drawer's colour image as a CUDA uint8 tensor sharing its memory."""
+    import torch
+
+    ptr = drawer.color_device_ptr(image_index)
+    full = torch.as_tensor(_DevicePtr(ptr, (drawer.height, drawer.width, 4)), device="cuda:%d" % drawer.cfg.device)
+    return full[y0:y1]
+
+
+def frame_hash(color):
+    """Order-sensitive 64-bit checksum of an RGBA8 frame (numpy), for cross-rank equality checks."""
+    a = np.ascontiguousarray(color).view(np.uint8).ravel().astype(np.uint64)
+    idx = np.arange(1, a.size + 1, dtype=np.uint64)
+    return int(((a + np.uint64(1)) * (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))).sum(dtype=np.uint64))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures from the CPU oracle:  python tests/golden/make_golden.py
+
+The reference ships no golden images and cannot run offline, so these vectors are outputs of the
+oracle (itself pinned by tests/test_oracle_math.py and tests/test_oracle_raster.py); they freeze
+its behaviour so that both the oracle and the HIP library are checked against fixed bits.
+Each fixture stores its inputs as well, so no random generator is involved when it is replayed.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle  # noqa: E402
+from renderer_amd import scenes  # noqa: E402
+from tests.util import IDENT, random_soup, soup_scene  # noqa: E402
+
+
+def save(name, scene, models, view, proj, out, extra=None):
+    d = dict(vertices=scene.vertices, indices=scene.indices, meshes=scene.meshes, objects=scene.objects,
+             transforms=scene.transforms, camera=scene.camera, size=np.array(scene.size),
+             models=models, view=view, proj=proj, color=out["color"], depth_bits=out["depth"].view(np.uint32),
+             prim=out["prim"])
+    for i, t in enumerate(scene.textures):
+        d["texture%d" % i] = t
+    d.update(extra or {})
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, out["stats"])
+
+
+def main():
+    oracle.build()
+    # 1. the reference's cube (config 1 pose) at 64x48
+    s = scenes.cube_scene(64, 48)
+    m = oracle.to_model(s.transforms)
+    v, p = oracle.camera(s.camera, 64, 48)
+    save("cube_64x48.npz", s, m, v, p, oracle.render(s, m, v, p, 64, 48))
+    # 2. the 64-cube demo world at 160x120
+    s = scenes.reference_demo_scene(width=160, height=120)
+    m = oracle.to_model(s.transforms)
+    v, p = oracle.camera(s.camera, 160, 120)
+    save("demo_160x120.npz", s, m, v, p, oracle.render(s, m, v, p, 160, 120))
+    # 3. a clip-space triangle soup with every awkward case, identity matrices
+    rng = np.random.default_rng(21)
+    s = soup_scene(random_soup(rng, 500, 96, 96), width=96, height=96)
+    m = np.tile(IDENT, (1, 1))
+    save("soup_96x96.npz", s, m, IDENT, IDENT, oracle.render(s, m, IDENT, IDENT, 96, 96))
+    # 4. spheres seen by a rotated, translated camera (exercises fps_view and Euler extraction)
+    s = scenes.sphere_field_scene(12, 8, 6.0, (-20.0, -4.0), 128, 96, n_textures=2, tex_size=32)
+    cam = oracle.identity_transforms(1)
+    oracle.translate(cam, 0, 1.5, -0.5, 2.0)
+    oracle.rotate(cam, 0, 12.0, -7.0, 0.0)
+    s.camera = cam
+    m = oracle.to_model(s.transforms)
+    v, p = oracle.camera(cam, 128, 96)
+    save("spheres_cam_128x96.npz", s, m, v, p, oracle.render(s, m, v, p, 128, 96))
+
+
+if __name__ == "__main__":
+    main()

@@ -32,3 +32,234 @@ def test_sphere_field_small(orc):
     ref = render_oracle(orc, s)
     got = render_hip(s)
     assert_frames_equal(got, ref, what="cfg2 quarter scale")
+
+
+IDENT = np.eye(4, dtype=np.float32).reshape(16)
+
+
+def _soup_pair(orc, scene, **kw):
+    w, h = scene.size
+    models = np.tile(IDENT, (len(scene.objects), 1))
+    shading = kw.pop("shading", 0)
+    ref = orc.render(scene, models, IDENT, IDENT, w, h, shading=shading, **kw)
+    got = render_hip(scene, models=models, view=IDENT, proj=IDENT, shading=shading, scissor=kw.get("scissor"))
+    return ref, got
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_triangle_soups(orc, seed):
+    """Degenerate, sub-pixel, huge, off-screen, near/far-crossing and guard-band-clipped triangles."""
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(seed)
+    w, h = [(96, 96), (200, 120), (333, 77), (64, 256)][seed - 1]  # frame sizes that are not tile multiples
+    s = soup_scene(random_soup(rng, 1500, w, h), width=w, height=h, objects_split=[700, 1, 799])
+    ref, got = _soup_pair(orc, s)
+    assert ref["stats"]["prims_clipped"] > 50
+    assert_frames_equal(got, ref, what="soup seed %d" % seed)
+
+
+def test_micro_triangles_dense(orc):
+    """Many sub-pixel triangles in few tiles: stresses the bin allocation and depth ties."""
+    from tests.util import soup_scene
+    rng = np.random.default_rng(77)
+    n = 60000
+    c = rng.uniform(-0.3, 0.3, (n, 1, 2))
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[..., :2] = c + rng.uniform(-0.02, 0.02, (n, 3, 2))
+    tris[..., 2] = np.round(rng.uniform(0.1, 0.9, (n, 1)) * 8) / 8  # few distinct depths -> many exact ties
+    s = soup_scene(tris, width=128, height=128)
+    ref, got = _soup_pair(orc, s)
+    assert_frames_equal(got, ref, what="dense micro triangles")
+
+
+@pytest.mark.parametrize("shading", [1, 2])
+def test_shading_modes(orc, shading):
+    """standard.frag:13 (vertex colour) and ui.frag:12 (colour x texture)."""
+    s = scenes.config_scene(2, scale=0.15)
+    ref = render_oracle(orc, s, shading=shading)
+    got = render_hip(s, shading=shading)
+    assert_frames_equal(got, ref, what="shading %d" % shading)
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(5)
+    tris = random_soup(rng, 600, 128, 128)
+    s = soup_scene(tris, colors=rng.uniform(0, 1, (600 * 3, 3)), width=128, height=128)
+    ref, got = _soup_pair(orc, s, shading=shading)
+    assert_frames_equal(got, ref, what="soup shading %d" % shading)
+
+
+def test_scissor_bands_equal_the_full_frame(orc):
+    s = scenes.config_scene(2, scale=0.3)
+    w, h = s.size
+    full = render_oracle(orc, s)
+    from renderer_amd import shard
+    for world in (2, 3):
+        for r in range(world):
+            y0, y1 = shard.band_rows(h, world, r)
+            got = render_hip(s, scissor=(y0, y1))
+            assert_frames_equal(got, full, rows=(y0, y1), what="band %d/%d" % (r, world))
+    got = render_hip(s, scissor=(37, 101))  # not tile aligned
+    assert_frames_equal(got, full, rows=(37, 101), what="odd band")
+
+
+def test_device_transform_kernels(orc):
+    """Transform::to_ubo and the rotation system on the device against the oracle, bit for bit."""
+    s = scenes.config_scene(3, scale=0.03)
+    w, h = s.size
+    with api.HipDrawer(w, h, coverage=True) as d:
+        d.update_scene(s)
+        assert d.read_models().tobytes() == orc.to_model(s.transforms).tobytes()
+        t = s.transforms.copy()
+        t["position"] += 1.0
+        d.update_transforms(t)
+        assert d.read_models().tobytes() == orc.to_model(t).tobytes()
+        for f in range(5):
+            d.rotation_system(3, f, 16.0)
+            orc.rotation_system(t, 3, f, 16.0)
+        assert d.read_transforms().tobytes() == t.tobytes()
+        assert d.read_models().tobytes() == orc.to_model(t).tobytes()
+        d.update_camera(s.camera)
+        d.draw(1)
+        got = {"color": d.read_color(1), "depth": d.read_depth(1), "prim": d.read_coverage(1)}
+    ref = orc.render(s, orc.to_model(t), *orc.camera(s.camera, w, h), w, h)
+    assert_frames_equal(got, ref, what="after 5 rotation steps")
+
+
+def test_moving_camera(orc):
+    s = scenes.config_scene(2, scale=0.25)
+    w, h = s.size
+    cams = scenes.orbit_cameras(3, 12, radius=30.0, target=(0.0, 0.0, -22.5))
+    with api.HipDrawer(w, h, coverage=True) as d:
+        d.update_scene(s)
+        for i in range(len(cams)):
+            d.update_camera(cams[i:i + 1])
+            d.draw(i & 1)
+            got = {"color": d.read_color(i & 1), "depth": d.read_depth(i & 1), "prim": d.read_coverage(i & 1)}
+            view, proj = orc.camera(cams[i:i + 1], w, h)
+            ref = orc.render(s, orc.to_model(s.transforms), view, proj, w, h)
+            assert (ref["prim"] != 0xFFFFFFFF).sum() > 100
+            assert_frames_equal(got, ref, what="camera %d" % i)
+
+
+def test_clip_positions_and_uniform_upload(orc):
+    s = scenes.config_scene(2, scale=0.1)
+    w, h = s.size
+    rng = np.random.default_rng(2)
+    models = orc.to_model(s.transforms)
+    models += rng.normal(0, 1e-3, models.shape).astype(np.float32)  # arbitrary matrices via update_uniforms
+    view, proj = orc.camera(s.camera, w, h)
+    ref = orc.render(s, models, view, proj, w, h, want_clip=True)
+    got = render_hip(s, models=models, want_clip=True)
+    assert_frames_equal(got, ref, what="update_uniforms")
+    rel = np.abs(got["clip"] - ref["clip"]) / np.maximum(np.abs(ref["clip"]), 1e-6)
+    assert rel.max() <= 1e-5  # the stated bar
+    assert np.array_equal(got["clip"].view(np.uint32), ref["clip"].view(np.uint32))  # what the contract gives
+
+
+def test_work_buffers_grow_on_demand(orc):
+    """A frame that needs more record / bin space than the first guess is re-rendered after growth."""
+    from tests.util import soup_scene
+    rng = np.random.default_rng(8)
+    n = 3000
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[..., :2] = rng.uniform(-1, 1, (n, 3, 2))  # every triangle spans many tiles
+    tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
+    s = soup_scene(tris, width=512, height=512)
+    models = np.tile(IDENT, (1, 1))
+    ref = orc.render(s, models, IDENT, IDENT, 512, 512)
+    got = render_hip(s, models=models, view=IDENT, proj=IDENT)
+    assert got["stats"]["redraws"] >= 1 and got["stats"]["bin_entries"] > 4096 + n // 2 + 4 * 256
+    assert_frames_equal(got, ref, what="regrown buffers")
+
+
+def test_error_behaviour(orc):
+    s = scenes.cube_scene(64, 64)
+    with api.HipDrawer(64, 64) as d:
+        with pytest.raises(api.SxeError) as e:
+            d.draw(0)
+        assert e.value.code == api.E_STATE
+        with pytest.raises(api.SxeError) as e:
+            d.update_uniforms(np.zeros((1, 16), np.float32))
+        assert e.value.code == api.E_STATE
+        d.set_textures([])
+        with pytest.raises(api.SxeError) as e:  # drawable without a texture (the reference panics: drawer.rs:317)
+            d.update_drawables(s.drawables())
+        assert e.value.code == api.E_INVALID and "texture" in str(e.value)
+        translucent = s.textures[0].copy()
+        translucent[3, 3, 3] = 128
+        with pytest.raises(api.SxeError) as e:
+            d.set_textures([translucent])
+        assert e.value.code == api.E_INVALID and "opaque" in str(e.value)
+        d.update_scene(s)
+        with pytest.raises(api.SxeError) as e:
+            d.draw(0)  # no camera yet
+        assert e.value.code == api.E_STATE
+        d.update_camera(s.camera)
+        with pytest.raises(api.SxeError) as e:
+            d.draw(5)
+        assert e.value.code == api.E_INVALID
+        with pytest.raises(api.SxeError) as e:  # more matrices than objects (types.rs:51 asserts instead)
+            d.update_uniforms(np.zeros((2, 16), np.float32))
+        assert e.value.code == api.E_CAPACITY
+        with pytest.raises(api.SxeError) as e:
+            d.read_color(1)  # never drawn
+        assert e.value.code == api.E_STATE
+        with pytest.raises(api.SxeError):
+            d.read_coverage(0)  # drawn? no: and coverage was not requested
+        d.draw(0)
+        d.sync()
+        bad = s.drawables()
+        bad[0].indices = bad[0].indices.copy()
+        bad[0].indices[5] = 24
+        with pytest.raises(api.SxeError) as e:
+            d.update_drawables(bad)
+        assert e.value.code == api.E_INVALID and "out of range" in str(e.value)
+        # the context is still usable after errors
+        d.update_scene(s)
+        d.draw(0)
+        assert (d.read_depth(0) < 1.0).sum() > 100
+
+
+def test_rerender_is_idempotent_and_images_are_independent(orc):
+    s = scenes.config_scene(2, scale=0.2)
+    w, h = s.size
+    with api.HipDrawer(w, h, n_images=3, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        a = d.read_color(0)
+        t = s.transforms.copy()
+        t["position"][:, 0] += 0.5
+        d.update_transforms(t)
+        d.draw(1)
+        d.update_transforms(s.transforms)
+        d.draw(2)
+        assert np.array_equal(d.read_color(0), a) and np.array_equal(d.read_color(2), a)
+        assert not np.array_equal(d.read_color(1), a)
+
+
+def test_full_size_config3_against_oracle(orc):
+    """The benchmark workload itself: 10.24 M triangles at 3840x2160, compared with the
+    band-parallel oracle, plus size-independent properties (idempotence, band union)."""
+    s = scenes.config_scene(3)
+    w, h = s.size
+    with api.HipDrawer(w, h, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.rotation_system(3, 0, 16.0)
+        d.draw(0)
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+        t = d.read_transforms()
+        d.draw(1)
+        assert np.array_equal(d.read_color(1), got["color"]) and np.array_equal(d.read_depth(1), got["depth"])
+        st = d.stats()
+    assert st["prims"] == 10240000
+    ref = orc.render(s, orc.to_model(t), *orc.camera(s.camera, w, h), w, h, threads=16)
+    assert_frames_equal(got, ref, what="config 3 full size")
+    from renderer_amd import shard
+    y0, y1 = shard.band_rows(h, 4, 2)
+    with api.HipDrawer(w, h, coverage=True, scissor=(y0, y1)) as d:
+        d.update_scene(s, transforms=t)
+        d.update_camera(s.camera)
+        d.draw(0)
+        band = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+    assert_frames_equal(band, ref, rows=(y0, y1), what="config 3 band 2/4")

@@ -55,3 +55,82 @@ def assert_frames_equal(a, b, rows=None, what=""):
     ca, cb = a["color"][sl].astype(np.int16), b["color"][sl].astype(np.int16)
     diff = np.abs(ca - cb).max() if ca.size else 0
     assert diff == 0, "%s colour differs by up to %d LSB at %d pixels" % (what, diff, int((ca != cb).any(axis=-1).sum()))
+
+
+def soup_scene(positions, uvs=None, colors=None, textures=None, width=64, height=64, objects_split=None, tex_ids=None):
+    """A scene whose vertices are already in clip space (w = 1): render it with identity
+    matrices.  positions: (n_tri, 3, 3) float32 (x, y in NDC, z in [0,1] visible).
+    objects_split: list of triangle counts per object (default one object)."""
+    from renderer_amd import scenes
+    from renderer_amd.api import MESH, OBJECT, VERTEX
+
+    positions = np.asarray(positions, dtype=np.float32).reshape(-1, 3, 3)
+    n = len(positions)
+    v = np.zeros(3 * n, dtype=VERTEX)
+    v["pos"] = positions.reshape(-1, 3)
+    v["uv"] = np.tile(np.array([[0, 0], [1, 0], [0, 1]], dtype=np.float32), (n, 1)) if uvs is None else np.asarray(uvs, np.float32).reshape(-1, 2)
+    v["color"] = 1.0 if colors is None else np.asarray(colors, np.float32).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    split = [n] if objects_split is None else list(objects_split)
+    assert sum(split) == n
+    meshes, first = [], 0
+    for k in split:
+        meshes.append((3 * first, 3 * k, 3 * first, 3 * k))
+        first += k
+    meshes = np.array(meshes, dtype=MESH)
+    # indices are mesh-local
+    for (fv, nv, fi, ni) in meshes:
+        idx[fi:fi + ni] -= fv
+    objects = np.zeros(len(split), dtype=OBJECT)
+    objects["mesh"] = np.arange(len(split))
+    objects["texture"] = 0 if tex_ids is None else tex_ids
+    objects["rendered"] = 1
+    tr = api.identity_transforms(1).repeat(len(split))
+    texs = [scenes.checker_texture(64, 5)] if textures is None else textures
+    return scenes.Scene(v, idx, meshes, objects, np.ascontiguousarray(tr), texs, size=(width, height), name="soup")
+
+
+def px_to_ndc(p, size):
+    """Pixel coordinate (may be fractional) -> NDC so that the viewport map returns it exactly
+    (size must be a power of two for exactness)."""
+    return 2.0 * np.asarray(p, dtype=np.float64) / size - 1.0
+
+
+IDENT = np.eye(4, dtype=np.float32).reshape(16)
+
+
+def random_soup(rng, n, width, height, kinds=("tiny", "small", "medium", "large", "offscreen", "degenerate", "near", "huge")):
+    """Seeded triangle soup in clip space (w = 1) with the awkward cases the rasteriser must survive."""
+    tris = np.zeros((n, 3, 3), dtype=np.float32)
+    for i in range(n):
+        kind = kinds[rng.integers(len(kinds))]
+        c = rng.uniform(-1.1, 1.1, 2)
+        z = rng.uniform(0.05, 0.95, 3)
+        if kind == "tiny":
+            r = 2.0 / width
+        elif kind == "small":
+            r = 6.0 / width
+        elif kind == "medium":
+            r = 0.2
+        elif kind == "large":
+            r = 1.5
+        elif kind == "offscreen":
+            c = rng.uniform(1.5, 3.0, 2) * rng.choice([-1, 1], 2)
+            r = 0.4
+        elif kind == "degenerate":
+            r = 0.3
+        elif kind == "near":
+            r = 0.6
+            z = rng.uniform(-0.5, 1.5, 3)  # crosses z = 0 and / or z = w
+        else:  # huge: forces the guard-band clipper
+            r = rng.uniform(5.0, 40.0)
+        p = c[None, :] + rng.uniform(-r, r, (3, 2))
+        if kind == "degenerate":
+            p[2] = p[0] if rng.random() < 0.5 else 0.5 * (p[0] + p[1])
+        tris[i, :, :2] = p
+        tris[i, :, 2] = z
+    # snap some vertices onto exact pixel centres / corners to exercise the fill rule
+    m = rng.random((n, 3)) < 0.3
+    snap = np.round((tris[..., :2] + 1) * 0.5 * np.array([width, height]) * 2) / 2
+    tris[..., :2][m] = (snap[m] / np.array([width, height]) * 2 - 1).astype(np.float32)
+    return tris
