@@ -173,6 +173,9 @@ int sxe_read_transforms(sxe_ctx *ctx, sxe_transform *transforms, size_t size_byt
 /* Device address of an image's RGBA8 rows (for a zero-copy RCCL tile gather). */
 int sxe_color_device_ptr(sxe_ctx *ctx, uint32_t image_index, void **ptr);
 int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
+/* Diagnostics: bin occupancy of the last frame, one count per rendered tile in row-major tile
+ * order (load-balance analysis; no counterpart in the reference). */
+int sxe_read_tile_counts(sxe_ctx *ctx, uint32_t *counts, size_t size_bytes);
 int sxe_get_stats(sxe_ctx *ctx, sxe_frame_stats *out);
 
 /* ---- host-side Transform / camera maths (no device needed) ---- */

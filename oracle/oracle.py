@@ -35,7 +35,7 @@ class Texture(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("prims", "prims_rejected", "prims_clipped", "subtris",
                                           "subtris_culled", "fragments_tested", "fragments_covered",
-                                          "fragments_passed")]
+                                          "fragments_passed", "subtris_empty")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

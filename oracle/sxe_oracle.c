@@ -483,6 +483,7 @@ static void raster_triangle(frame *f, const cvert tri[3], uint32_t prim_id, int3
     int tl[3];
     for (int e = 0; e < 3; ++e) tl[e] = (ey[e] < 0) || (ey[e] == 0 && ex[e] > 0); /* top-left rule */
 
+    uint64_t covered_before = f->st.fragments_covered;
     for (int32_t j = py0; j <= py1; ++j) {
         for (int32_t i = px0; i <= px1; ++i) {
             int64_t sx = 256 * (int64_t)i + 128, sy = 256 * (int64_t)j + 128;
@@ -529,6 +530,7 @@ static void raster_triangle(frame *f, const cvert tri[3], uint32_t prim_id, int3
             px[3] = unorm8_encode(sa + da * ia);
         }
     }
+    if (f->st.fragments_covered == covered_before) f->st.subtris_empty++;
 }
 
 static int validate(const orc_config *cfg, const orc_mesh *meshes, uint32_t n_meshes,

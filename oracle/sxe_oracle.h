@@ -69,6 +69,7 @@ typedef struct {
 typedef struct {
     uint64_t prims, prims_rejected, prims_clipped, subtris, subtris_culled;
     uint64_t fragments_tested, fragments_covered, fragments_passed;
+    uint64_t subtris_empty; /* set up and scanned, but no sample point inside */
 } orc_stats;
 
 /* ---- deterministic elementary functions (the numeric contract both sides implement) ---- */

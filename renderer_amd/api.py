@@ -28,7 +28,7 @@ EXPORTS = [
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
     "sxe_rotation_system", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
     "sxe_read_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
-    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_stats",
+    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_stats", "sxe_read_tile_counts",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
     "sxe_camera_matrices",
 ]
@@ -122,7 +122,7 @@ def lib():
         L.sxe_sync.argtypes = [C.c_void_p]
         for name in ("sxe_read_color", "sxe_read_depth", "sxe_read_coverage"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
-        for name in ("sxe_read_clip_positions", "sxe_read_models", "sxe_read_transforms"):
+        for name in ("sxe_read_clip_positions", "sxe_read_models", "sxe_read_transforms", "sxe_read_tile_counts"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sxe_color_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.sxe_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
@@ -196,7 +196,7 @@ class HipDrawer:
     """The `Drawer` trait over the HIP library."""
 
     def __init__(self, width, height, device=0, n_images=2, scissor=None, shading=SHADE_TEXTURE,
-                 coverage=False, timing=False, clear=None, fov_deg=None, z_near=None, z_far=None):
+                 coverage=False, timing=False, clear=None, fov_deg=None, z_near=None, z_far=None, debug_flags=0):
         self._L = lib()
         self._ctx = C.c_void_p()
         cfg = Config()
@@ -208,7 +208,7 @@ class HipDrawer:
             if cfg.scissor_y0 == 0 and cfg.scissor_y1 == 0:
                 raise SxeError(E_INVALID, "empty scissor")
         cfg.shading = shading
-        cfg.flags = (FLAG_WRITE_COVERAGE if coverage else 0) | (FLAG_TIMING if timing else 0)
+        cfg.flags = (FLAG_WRITE_COVERAGE if coverage else 0) | (FLAG_TIMING if timing else 0) | debug_flags
         if clear is not None:
             cfg.clear = (C.c_float * 4)(*clear)
         if fov_deg is not None:
@@ -348,6 +348,12 @@ class HipDrawer:
         p = C.c_void_p()
         self._check(self._L.sxe_color_device_ptr(self._ctx, image_index, C.byref(p)))
         return p.value
+
+    def tile_counts(self):
+        n = int(self.stats()["tiles"])
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self._L.sxe_read_tile_counts(self._ctx, _p(out), out.nbytes))
+        return out[:n]
 
     def timings(self):
         t = Timings()

@@ -366,6 +366,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ra.clear_code = srgb_encode_host(c->cfg.clear[0]) | (srgb_encode_host(c->cfg.clear[1]) << 8) |
                     (srgb_encode_host(c->cfg.clear[2]) << 16) | (unorm8_host(c->cfg.clear[3]) << 24);
     ra.shading = c->cfg.shading;
+    ra.debug = c->cfg.flags & kDebugMask;
     SXE_HIP(c, launch_raster_shade(ra, s));
     if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_RASTER], s));
 
@@ -778,6 +779,18 @@ int sxe_color_device_ptr(sxe_ctx *c, uint32_t image_index, void **ptr)
     if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
     if (!ptr || image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "bad image index or null pointer");
     *ptr = c->images[image_index].color.p;
+    return SXE_OK;
+}
+
+int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    const size_t need = (size_t)c->g.n_tiles * 4;
+    if (!counts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    rc = sxe_sync(c);
+    if (rc) return rc;
+    if (need) SXE_HIP(c, hipMemcpy(counts, c->tile_counters.p, need, hipMemcpyDeviceToHost));
     return SXE_OK;
 }
 

@@ -16,6 +16,10 @@ constexpr int kRasterThreads = 256;
 constexpr float kGuard = 4.0f;     // guard band: x,y are clipped at +-kGuard*w (power of two)
 constexpr int kMaxFan = 7;         // a triangle clipped by six planes has at most 9 corners
 constexpr unsigned long long kVisEmpty = ~0ull;
+// development-only switches carried in sxe_config.flags (timing experiments; outputs are wrong)
+constexpr uint32_t kDebugSkipRaster = 1u << 30, kDebugSkipResolve = 1u << 31;
+constexpr uint32_t kDebugSkipSmall = 1u << 28, kDebugSkipLarge = 1u << 29, kDebugSkipAtomic = 1u << 27;
+constexpr uint32_t kDebugMask = 31u << 27;
 
 struct MeshDev {
     uint32_t vtx_base, n_vtx, idx_base, n_tri;
@@ -126,6 +130,7 @@ struct RasterArgs {
     uint32_t *out_prim;   // may be null
     uint32_t clear_code;  // encoded clear colour, little-endian RGBA
     uint32_t shading;
+    uint32_t debug;
 };
 
 // Launchers (defined in sxe_kernels.hip). All enqueue on `s` and return the launch status.

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
-    const uint32_t n = a.tile_count[tile], off = a.tile_off[tile];
+    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : a.tile_count[tile], off = a.tile_off[tile];
     for (uint32_t base = (uint32_t)wave * 64u; base < n; base += kRasterThreads) {
         const uint32_t e = base + (uint32_t)lane;
         const bool valid = e < n;
@@ -621,6 +621,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
             const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
             small = nonempty && bw * bh <= 16 && (xmax - xmin) < 16384 && (ymax - ymin) < 16384;
             large = nonempty && !small;
+            if (a.debug & kDebugSkipSmall) small = false;
+            if (a.debug & kDebugSkipLarge) large = false;
             if (small) {
                 // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
                 const int32_t ex0 = r.x2 - r.x1, ey0 = r.y2 - r.y1;
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                         if (z < 1.0f) {
                             const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | slot;
                             unsigned long long *p = &vis[(j - tpy) * kTile + (i - tpx)];
-                            if (key < *p) atomicMin(p, key);
+                            if (!(a.debug & kDebugSkipAtomic) && key < *p) atomicMin(p, key);
                         }
                     }
                     if (++i > bx1) { i = bx0; ++j; }
@@ -688,6 +690,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
         }
     }
     __syncthreads();
+    if (a.debug & kDebugSkipResolve) return;
 
     // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target ----
     const float clr_r = s_dec[a.clear_code & 255], clr_g = s_dec[(a.clear_code >> 8) & 255];
