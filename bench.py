@@ -168,7 +168,7 @@ def main():
         covered_px = int((cov < 1.0).sum())
         tex_bytes = sum(int(t.nbytes) for t in scene.textures)
         ab = algorithmic_bytes(stats, width, height if not sortfirst else (scissor[1] - scissor[0]), covered_px, tex_bytes)
-        stage_ms = {"setup": kern["setup_count_ms"] + kern["setup_emit_ms"], "raster_shade": kern["raster_shade_ms"]}
+        stage_ms = {"setup": kern["setup_ms"], "raster_shade": kern["raster_shade_ms"]}
         dom = max(stage_ms, key=stage_ms.get)
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic = None

@@ -108,13 +108,13 @@ typedef struct {
 
 /* Per-kernel device times of the last synchronised frame, milliseconds (needs SXE_FLAG_TIMING). */
 typedef struct {
-    float transform_ms, object_ms, setup_count_ms, scan_ms, setup_emit_ms, raster_shade_ms, frame_ms;
+    float transform_ms, object_ms, setup_ms, scan_ms, bin_ms, raster_shade_ms, frame_ms;
 } sxe_timings;
 
 /* Work counters of the last synchronised frame. */
 typedef struct {
     uint64_t prims;        /* triangles submitted */
-    uint64_t records;      /* record slots reserved (surviving triangles incl. clip fans) */
+    uint64_t records;      /* triangles that survived setup */
     uint64_t bin_entries;  /* (triangle, tile) pairs */
     uint64_t tiles;        /* screen tiles rendered */
     uint64_t instance_vertices;

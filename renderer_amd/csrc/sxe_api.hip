@@ -55,7 +55,7 @@ struct Image {
     bool drawn = false;
 };
 
-enum { EV_BEGIN = 0, EV_OBJECT, EV_COUNT, EV_SCAN, EV_EMIT, EV_RASTER, EV_N };
+enum { EV_BEGIN = 0, EV_OBJECT, EV_SETUP, EV_SCAN, EV_BIN, EV_RASTER, EV_N };
 
 } // namespace
 
@@ -84,14 +84,17 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, blk_base, tile_counters /* count | fill */, tile_off, bins;
+    DevBuf<uint32_t> blk_count, tile_counters /* count | fill front | fill back */, tile_off, bins, object_mesh;
+    DevBuf<uint8_t> visible;
     DevBuf<RastRec> rast;
+    DevBuf<WideRec> wide;
+    DevBuf<ClipItem> clip_list;
     DevBuf<ShadeRec> shade;
     DevBuf<ColorRec> color;
     DevBuf<FrameCounters> counters;
     DevBuf<float4> clip;
     FrameCounters *h_counters = nullptr; // pinned
-    size_t rec_capacity = 0, bin_capacity = 0;
+    size_t fan_capacity = 0, bin_capacity = 0; // records past the per-workgroup segments; bin entries
 
     std::vector<Image> images;
     int last_image = -1;
@@ -168,6 +171,18 @@ struct HostObject {
     sxe_transform transform;
 };
 
+// Record arrays: 256 slots per setup work item, then fan_capacity slots for clipped fans.
+hipError_t reserve_records(sxe_ctx *c)
+{
+    const size_t n = (size_t)c->n_blocks * kSetupThreads + c->fan_capacity;
+    hipError_t e;
+    if ((e = c->rast.reserve(n)) != hipSuccess) return e;
+    if ((e = c->wide.reserve(n)) != hipSuccess) return e;
+    if ((e = c->shade.reserve(n)) != hipSuccess) return e;
+    if (c->cfg.shading != SXE_SHADE_TEXTURE && (e = c->color.reserve(n)) != hipSuccess) return e;
+    return c->clip_list.reserve(c->fan_capacity);
+}
+
 // Shared tail of update_drawables / update_instances: pools the meshes, derives the draw list
 // (src/renderer/drawer.rs:173-214, 481-487, 313-347) and uploads everything.
 int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<HostObject> &ho)
@@ -189,6 +204,17 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
         meshes[m].n_vtx = hm[m].nv;
         meshes[m].idx_base = (uint32_t)ni_total;
         meshes[m].n_tri = hm[m].ni / 3;
+        for (int k = 0; k < 3; ++k) {
+            float lo = 0.0f, hi = 0.0f;
+            for (uint32_t v = 0; v < hm[m].nv; ++v) {
+                const float p = hm[m].v[v].pos[k];
+                if (v == 0 || p < lo) lo = p;
+                if (v == 0 || p > hi) hi = p;
+                if (p != p) { lo = -INFINITY; hi = INFINITY; break; } // NaN coordinate: never cull this mesh as a whole
+            }
+            meshes[m].lo[k] = lo;
+            meshes[m].hi[k] = hi;
+        }
         nv_total += (hm[m].nv + 3u) & ~3u;
         ni_total += hm[m].ni;
         if (nv_total > 0xFFFFFFF0ull || ni_total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "scene pools exceed 2^32 elements");
@@ -233,6 +259,8 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
         for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) blocks.push_back({(uint32_t)d, t0});
         prims += nt;
         if (prims > SXE_MAX_PRIMS) return fail(c, SXE_E_CAPACITY, "more than %u triangles per frame", SXE_MAX_PRIMS);
+        // record slots are 32-bit: 256 per work item plus the region for clipped fans
+        if (blocks.size() > (1u << 23)) return fail(c, SXE_E_CAPACITY, "more than 2^23 setup work items (256 triangles each)");
     }
     // vertex-kernel work items and the clip-position layout: objects in caller order
     std::vector<VBlockDesc> vblocks;
@@ -267,9 +295,12 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     SXE_HIP(c, up(c->vblocks, vblocks));
     SXE_HIP(c, up(c->models, models));
     SXE_HIP(c, up(c->transforms, transforms));
+    std::vector<uint32_t> object_mesh(ho.size());
+    for (size_t o = 0; o < ho.size(); ++o) object_mesh[o] = ho[o].mesh;
+    SXE_HIP(c, up(c->object_mesh, object_mesh));
+    SXE_HIP(c, c->visible.reserve(std::max<size_t>(ho.size(), 1)));
     SXE_HIP(c, c->pvm.reserve(std::max<size_t>(models.size(), 16)));
     SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1)));
-    SXE_HIP(c, c->blk_base.reserve(std::max<size_t>(blocks.size(), 1)));
 
     c->n_meshes = (uint32_t)hm.size();
     c->n_objects = (uint32_t)ho.size();
@@ -282,19 +313,29 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     c->have_scene = true;
 
     // first guess for the work buffers; sxe_sync grows them and redraws when a frame needs more
-    const size_t want_rec = std::max<size_t>(4096, (size_t)(prims / 2 + 1024));
+    // every setup work item owns 256 record slots; fans of clipped triangles follow them
+    if (c->fan_capacity < 4096) c->fan_capacity = 4096;
+    SXE_HIP(c, reserve_records(c));
     const size_t want_bin = std::max<size_t>(4096, (size_t)(prims / 2 + 4 * (uint64_t)c->g.n_tiles));
-    if (want_rec > c->rec_capacity) {
-        SXE_HIP(c, c->rast.reserve(want_rec));
-        SXE_HIP(c, c->shade.reserve(want_rec));
-        if (c->cfg.shading != SXE_SHADE_TEXTURE) SXE_HIP(c, c->color.reserve(want_rec));
-        c->rec_capacity = want_rec;
-    }
     if (want_bin > c->bin_capacity) {
         SXE_HIP(c, c->bins.reserve(want_bin));
         c->bin_capacity = want_bin;
     }
     return SXE_OK;
+}
+
+ObjectArgs object_args(sxe_ctx *c)
+{
+    ObjectArgs oa;
+    oa.models = c->models.p;
+    oa.pv = c->pv;
+    oa.pvm = c->pvm.p;
+    oa.meshes = c->meshes.p;
+    oa.object_mesh = c->object_mesh.p;
+    oa.visible = c->visible.p;
+    oa.n = c->n_objects;
+    oa.g = c->g;
+    return oa;
 }
 
 int enqueue_frame(sxe_ctx *c, uint32_t image_index)
@@ -304,9 +345,10 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     hipStream_t s = c->stream;
     const uint32_t nt = c->g.n_tiles;
 
+    const size_t ntc = std::max<uint32_t>(nt, 1);
     if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_BEGIN], s));
-    SXE_HIP(c, launch_object(c->models.p, c->pv, c->pvm.p, c->n_objects, s));
-    SXE_HIP(c, hipMemsetAsync(c->tile_counters.p, 0, 2 * (size_t)std::max<uint32_t>(nt, 1) * sizeof(uint32_t), s));
+    SXE_HIP(c, launch_object(object_args(c), s));
+    SXE_HIP(c, hipMemsetAsync(c->tile_counters.p, 0, 3 * ntc * sizeof(uint32_t), s));
     SXE_HIP(c, hipMemsetAsync(c->counters.p, 0, sizeof(FrameCounters), s));
     if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_OBJECT], s));
 
@@ -317,44 +359,58 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sa.insts = c->insts.p;
     sa.blocks = c->blocks.p;
     sa.pvm = c->pvm.p;
+    sa.visible = c->visible.p;
     sa.n_blocks = c->n_blocks;
     sa.shading = c->cfg.shading;
     sa.g = c->g;
     sa.blk_count = c->blk_count.p;
-    sa.blk_base = c->blk_base.p;
     sa.tile_count = c->tile_counters.p;
-    sa.tile_off = c->tile_off.p;
-    sa.tile_fill = c->tile_counters.p + std::max<uint32_t>(nt, 1);
     sa.rast = c->rast.p;
+    sa.wide = c->wide.p;
     sa.shade = c->shade.p;
     sa.color = c->color.p;
-    sa.bins = c->bins.p;
+    sa.fan_capacity = (uint32_t)c->fan_capacity;
+    sa.clip_list = c->clip_list.p;
     sa.counters = c->counters.p;
-    SXE_HIP(c, launch_setup_count(sa, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_COUNT], s));
+    SXE_HIP(c, launch_setup(sa, s));
+    SXE_HIP(c, launch_clip(sa, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_SETUP], s));
 
     ScanArgs sc;
     sc.blk_count = c->blk_count.p;
-    sc.blk_base = c->blk_base.p;
     sc.n_blocks = c->n_blocks;
     sc.tile_count = sa.tile_count;
     sc.tile_off = c->tile_off.p;
     sc.n_tiles = nt;
-    sc.rec_capacity = (uint32_t)std::min<size_t>(c->rec_capacity, 0xFFFFFFFFu);
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
     sc.counters = c->counters.p;
     SXE_HIP(c, launch_scan(sc, s));
     if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_SCAN], s));
 
-    SXE_HIP(c, launch_setup_emit(sa, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_EMIT], s));
+    BinArgs ba;
+    ba.g = c->g;
+    ba.blk_count = c->blk_count.p;
+    ba.n_blocks = c->n_blocks;
+    ba.fan_blocks = (uint32_t)((c->fan_capacity + kSetupThreads - 1) / kSetupThreads);
+    ba.rast = c->rast.p;
+    ba.wide = c->wide.p;
+    ba.tile_count = sa.tile_count;
+    ba.tile_off = c->tile_off.p;
+    ba.fill_front = c->tile_counters.p + ntc;
+    ba.fill_back = c->tile_counters.p + 2 * ntc;
+    ba.bins = c->bins.p;
+    ba.counters = c->counters.p;
+    SXE_HIP(c, launch_bin(ba, s));
+    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_BIN], s));
 
     RasterArgs ra;
     ra.g = c->g;
     ra.tile_count = sa.tile_count;
     ra.tile_off = c->tile_off.p;
+    ra.fill_front = ba.fill_front;
     ra.bins = c->bins.p;
     ra.rast = c->rast.p;
+    ra.wide = c->wide.p;
     ra.shade = c->shade.p;
     ra.color = c->color.p;
     ra.counters = c->counters.p;
@@ -491,7 +547,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(2 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_counters.reserve(3 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_off.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile offsets)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
@@ -508,7 +564,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->pvm.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->blk_base.release(); c->tile_counters.release(); c->tile_off.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->visible.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
@@ -677,13 +733,14 @@ int sxe_sync(sxe_ctx *c)
     if (!c->frame_pending) return SXE_OK;
     for (int attempt = 0; attempt < 4 && c->h_counters->overflow; ++attempt) {
         // a work buffer was too small: grow to what the frame asked for and render it again
-        const size_t need_rec = (size_t)c->h_counters->total_records + (size_t)c->h_counters->total_records / 4 + 1024;
+        // a full clip list hides how many fans its overflow would have produced: at most 7 each
+        const size_t fans = std::max<size_t>(c->h_counters->fan_records,
+                                             c->h_counters->clip_count > c->fan_capacity ? (size_t)c->h_counters->clip_count * kMaxFan : 0);
+        const size_t need_fan = fans + fans / 4 + 1024;
         const size_t need_bin = (size_t)c->h_counters->total_pairs + (size_t)c->h_counters->total_pairs / 4 + 1024;
-        if (need_rec > c->rec_capacity) {
-            SXE_HIP(c, c->rast.reserve(need_rec));
-            SXE_HIP(c, c->shade.reserve(need_rec));
-            if (c->cfg.shading != SXE_SHADE_TEXTURE) SXE_HIP(c, c->color.reserve(need_rec));
-            c->rec_capacity = need_rec;
+        if (need_fan > c->fan_capacity) {
+            c->fan_capacity = need_fan;
+            SXE_HIP(c, reserve_records(c));
         }
         if (need_bin > c->bin_capacity) {
             SXE_HIP(c, c->bins.reserve(need_bin));
@@ -708,9 +765,9 @@ int sxe_sync(sxe_ctx *c)
         float ms[EV_N] = {};
         for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i - 1], c->ev[i]));
         c->timings.object_ms = ms[EV_OBJECT];
-        c->timings.setup_count_ms = ms[EV_COUNT];
+        c->timings.setup_ms = ms[EV_SETUP];
         c->timings.scan_ms = ms[EV_SCAN];
-        c->timings.setup_emit_ms = ms[EV_EMIT];
+        c->timings.bin_ms = ms[EV_BIN];
         c->timings.raster_shade_ms = ms[EV_RASTER];
         SXE_HIP(c, hipEventElapsedTime(&c->timings.frame_ms, c->ev[EV_BEGIN], c->ev[EV_RASTER]));
         c->timings.transform_ms = 0.0f;
@@ -742,7 +799,7 @@ int sxe_read_clip_positions(sxe_ctx *c, float *clip, size_t size_bytes)
     const size_t need = (size_t)c->n_inst_vertices * 16;
     if (!clip || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     SXE_HIP(c, c->clip.reserve(std::max<size_t>(c->n_inst_vertices, 1)));
-    SXE_HIP(c, launch_object(c->models.p, c->pv, c->pvm.p, c->n_objects, c->stream));
+    SXE_HIP(c, launch_object(object_args(c), c->stream));
     SXE_HIP(c, launch_vertex(c->pos_x.p, c->pos_y.p, c->pos_z.p, c->meshes.p, c->vblocks.p, c->n_vblocks, c->pvm.p,
                              c->clip.p, c->stream));
     SXE_HIP(c, hipStreamSynchronize(c->stream));

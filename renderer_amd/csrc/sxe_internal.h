@@ -11,18 +11,26 @@ namespace sxe {
 
 constexpr int kTile = 32;          // screen tile edge, pixels: one workgroup rasterises one tile
 constexpr int kTilePixels = kTile * kTile;
-constexpr int kSetupThreads = 256; // triangles per setup workgroup
+constexpr int kSetupThreads = 256; // triangles per setup workgroup = record slots per segment
 constexpr int kRasterThreads = 256;
 constexpr float kGuard = 4.0f;     // guard band: x,y are clipped at +-kGuard*w (power of two)
 constexpr int kMaxFan = 7;         // a triangle clipped by six planes has at most 9 corners
+constexpr int kSmallBox = 8;       // bin entries whose pixel box holds <= this many pixels go to the
+                                   // front of a tile's bin, the others to the back
+constexpr int kLaneBox = 64;       // largest pixel box one lane walks alone; larger ones take a whole wave
 constexpr unsigned long long kVisEmpty = ~0ull;
+constexpr int32_t kNoRaster = INT32_MIN; // RastRec.x0 of a slot that holds no triangle to rasterise
 // development-only switches carried in sxe_config.flags (timing experiments; outputs are wrong)
 constexpr uint32_t kDebugSkipRaster = 1u << 30, kDebugSkipResolve = 1u << 31;
 constexpr uint32_t kDebugSkipSmall = 1u << 28, kDebugSkipLarge = 1u << 29, kDebugSkipAtomic = 1u << 27;
 constexpr uint32_t kDebugMask = 31u << 27;
 
+// overflow bits of FrameCounters::overflow
+constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
+
 struct MeshDev {
     uint32_t vtx_base, n_vtx, idx_base, n_tri;
+    float lo[3], hi[3]; // object-space bounding box of the mesh
 };
 
 // One drawn object in draw order (texture groups ascending, caller order inside a group;
@@ -34,7 +42,7 @@ struct InstDev {
     uint32_t prim_base; // id of this object's first triangle in the frame
 };
 
-struct BlockDesc { // work item of the setup kernels: 256 consecutive triangles of one object
+struct BlockDesc { // work item of the setup kernel: 256 consecutive triangles of one object
     uint32_t inst, tri_start;
 };
 
@@ -47,21 +55,35 @@ struct TexDev {
     uint32_t width, height, pad;
 };
 
-// Everything the coverage/depth loop needs about one screen triangle (48 B, three 16-B loads).
+// Record storage.  Setup workgroup b owns slots [256 b, 256 b + 256) and fills them from the front
+// in submission order, so a slot number orders triangles as they were submitted.  Triangles cut by
+// the clipper keep one such slot (their "order") and put their fan triangles into the extra
+// region that starts at slot 256 * n_blocks.
+
+// Everything the coverage/depth loop needs about one screen triangle (32 B, two 16-B loads).
+// Corners are 24.8 fixed point, oriented so that the doubled area is > 0.  Corners 1 and 2 are
+// stored as 16-bit offsets from corner 0 (x in the low half, y in the high half); a triangle whose
+// offsets do not fit sets d1 = kWideTri and keeps its corners in the WideRec of the same slot.
 struct __attribute__((aligned(16))) RastRec {
-    int32_t x0, y0, x1, y1;
-    int32_t x2, y2;
-    float z0, dz1;
-    float dz2, rA;
-    uint32_t prim;
-    int32_t texture;
+    int32_t x0, y0;   // x0 == kNoRaster: nothing to rasterise in this slot
+    uint32_t d1, d2;
+    float z0, dz1, dz2;
+    uint32_t order;   // low half of the visibility key: the slot that ranks this triangle in submission order
+};
+constexpr uint32_t kWideTri = 0x80008000u; // both offsets -32768: never produced by a packed triangle
+
+struct __attribute__((aligned(16))) WideRec {
+    int32_t x1, y1, x2, y2;
 };
 
 // Perspective-correct attribute planes of the same triangle, read once per visible pixel.
 struct __attribute__((aligned(16))) ShadeRec {
     float iw0, diw1, diw2, uw0;
     float duw1, duw2, vw0, dvw1;
-    float dvw2, pad0, pad1, pad2;
+    float dvw2;
+    uint32_t prim;       // primitive id reported in the coverage buffer
+    uint32_t fan_base;   // for a clipped triangle's order slot: first fan record
+    uint32_t tex_fan;    // texture index in the low 24 bits, fan triangle count in the high 8 (0: ordinary)
 };
 
 struct __attribute__((aligned(16))) ColorRec {
@@ -71,7 +93,18 @@ struct __attribute__((aligned(16))) ColorRec {
 };
 
 struct FrameCounters {
-    uint32_t total_records, total_pairs, overflow, pad;
+    uint32_t total_records; // surviving triangles (order slots)
+    uint32_t total_pairs;   // (triangle, tile) bin entries
+    uint32_t fan_records;   // fan triangles of clipped primitives
+    uint32_t overflow;      // kOverflow* bits
+    uint32_t clip_count;    // triangles handed to the clip kernel
+    uint32_t pad[3];
+};
+
+// A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
+// leaves the clipping to k_clip.
+struct ClipItem {
+    uint32_t inst, tri, slot;
 };
 
 struct FrameGeom {
@@ -81,45 +114,72 @@ struct FrameGeom {
     float half_w, half_h;
 };
 
+struct ObjectArgs {
+    const float *models;
+    Mat4 pv;
+    float *pvm;
+    const MeshDev *meshes;
+    const uint32_t *object_mesh; // mesh of every object (caller order)
+    uint8_t *visible;            // 0: the whole object is outside the view volume or the scissor band
+    uint32_t n;
+    FrameGeom g;
+};
+
 struct SetupArgs {
     const sxe_vertex *vertices;
     const uint32_t *indices;
     const MeshDev *meshes;
     const InstDev *insts;
     const BlockDesc *blocks;
-    const float *pvm; // 16 floats per object (caller order)
+    const float *pvm;          // 16 floats per object (caller order)
+    const uint8_t *visible;
     uint32_t n_blocks;
     uint32_t shading;
     FrameGeom g;
-    uint32_t *blk_count;
-    const uint32_t *blk_base;
+    uint32_t *blk_count;       // survivors per workgroup
     uint32_t *tile_count;
-    const uint32_t *tile_off;
-    uint32_t *tile_fill;
     RastRec *rast;
+    WideRec *wide;
     ShadeRec *shade;
     ColorRec *color;
-    uint32_t *bins;
+    uint32_t fan_capacity;     // records available past slot 256 * n_blocks; also the clip list's length
+    ClipItem *clip_list;
     FrameCounters *counters;
 };
 
 struct ScanArgs {
     const uint32_t *blk_count;
-    uint32_t *blk_base;
     uint32_t n_blocks;
     const uint32_t *tile_count;
     uint32_t *tile_off;
     uint32_t n_tiles;
-    uint32_t rec_capacity, bin_capacity;
+    uint32_t bin_capacity;
     FrameCounters *counters;
+};
+
+struct BinArgs {
+    FrameGeom g;
+    const uint32_t *blk_count;
+    uint32_t n_blocks;
+    uint32_t fan_blocks;       // workgroups launched for the fan region
+    const RastRec *rast;
+    const WideRec *wide;
+    const uint32_t *tile_count;
+    const uint32_t *tile_off;
+    uint32_t *fill_front;      // per tile: entries with small pixel boxes, filled upwards
+    uint32_t *fill_back;       // per tile: the others, filled downwards from the end of the bin
+    uint32_t *bins;
+    const FrameCounters *counters;
 };
 
 struct RasterArgs {
     FrameGeom g;
     const uint32_t *tile_count;
     const uint32_t *tile_off;
+    const uint32_t *fill_front;
     const uint32_t *bins;
     const RastRec *rast;
+    const WideRec *wide;
     const ShadeRec *shade;
     const ColorRec *color;
     const FrameCounters *counters;
@@ -134,16 +194,17 @@ struct RasterArgs {
 };
 
 // Launchers (defined in sxe_kernels.hip). All enqueue on `s` and return the launch status.
-hipError_t launch_object(const float *models, const Mat4 &pv, float *pvm, uint32_t n, hipStream_t s);
+hipError_t launch_object(const ObjectArgs &a, hipStream_t s);
 hipError_t launch_transform_to_model(const sxe_transform *t, float *models, uint32_t n, hipStream_t s);
 hipError_t launch_rotation_system(sxe_transform *t, float *models, uint32_t n, uint64_t seed,
                                   uint32_t frame, float delta_ms, hipStream_t s);
 hipError_t launch_vertex(const float *px, const float *py, const float *pz, const MeshDev *meshes,
                          const VBlockDesc *vblocks, uint32_t n_vblocks, const float *pvm,
                          float4 *clip, hipStream_t s);
-hipError_t launch_setup_count(const SetupArgs &a, hipStream_t s);
+hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
+hipError_t launch_clip(const SetupArgs &a, hipStream_t s);
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
-hipError_t launch_setup_emit(const SetupArgs &a, hipStream_t s);
+hipError_t launch_bin(const BinArgs &a, hipStream_t s);
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s);
 
 } // namespace sxe

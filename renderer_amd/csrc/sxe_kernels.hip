@@ -1,14 +1,17 @@
 // sxe_kernels.hip -- gfx950 kernels of the raster/shade path.
 //
 // Frame pipeline (all on one stream, no host round trip):
-//   k_object        PVM = (P*V)*M per object                              (standard.vert:28, matrix part)
-//   k_setup<false>  per triangle: vertex transform, cull/clip, snap, bbox; counts record slots per
-//                   workgroup and bin entries per screen tile
-//   k_scan          exclusive scans of both count arrays, capacity check
-//   k_setup<true>   same decisions again; writes triangle records in submission order and scatters
-//                   their slot numbers into the per-tile bins
+//   k_object        PVM = (P*V)*M per object (standard.vert:28, matrix part) and a conservative
+//                   whole-object visibility test
+//   k_setup         one thread per submitted triangle: vertex transform, trivial reject, clip,
+//                   perspective divide, snap, orientation, bounding box, exact coverage test for
+//                   tiny boxes; writes one record per surviving triangle in submission order and
+//                   counts bin entries per screen tile
+//   k_scan          exclusive scan of the tile counts, totals, capacity check
+//   k_bin           scatters record slots into the per-tile bins (small boxes to the front of a
+//                   bin, the others to its back)
 //   k_raster_shade  one workgroup per 32x32 tile: coverage + depth in LDS with 64-bit
-//                   (depth|slot) minima, then one deferred shade + store per pixel
+//                   (depth | order) minima, then one deferred shade + store per pixel
 //
 // What the kernels replace in the reference is fixed-function Vulkan state selected at
 // src/renderer/drawer.rs:652-705 plus the two shaders under src/data/shaders/.
@@ -41,23 +44,73 @@ static hipError_t ensure_tables()
     return hipSuccess;
 }
 
+// gl_Position = PVM * (pos, 1) with each row summed left to right (standard.vert:28).
+__device__ inline float4 transform_vertex(const float *__restrict__ pvm, float x, float y, float z)
+{
+    float4 r;
+    r.x = ((pvm[0] * x + pvm[4] * y) + pvm[8] * z) + pvm[12];
+    r.y = ((pvm[1] * x + pvm[5] * y) + pvm[9] * z) + pvm[13];
+    r.z = ((pvm[2] * x + pvm[6] * y) + pvm[10] * z) + pvm[14];
+    r.w = ((pvm[3] * x + pvm[7] * y) + pvm[11] * z) + pvm[15];
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Per-object kernels
 // ------------------------------------------------------------------------------------------
 
-__global__ void k_object(const float *__restrict__ models, Mat4 pv, float *__restrict__ pvm, uint32_t n)
+// PVM per object, plus: is the whole object certainly invisible?  The eight corners of the mesh's
+// bounding box are transformed like vertices; if all of them lie outside one plane of the view
+// volume by more than a bound on the rounding error of such a transform, every vertex of the mesh
+// does too, so every one of its triangles would be rejected one by one anyway.  The same holds
+// for objects that project wholly above or below the scissor rows.  Skipping such objects changes
+// no pixel.
+__global__ void k_object(ObjectArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= a.n) return;
     Mat4 M;
-    const float4 *src = reinterpret_cast<const float4 *>(models + 16 * (size_t)i);
+    const float4 *src = reinterpret_cast<const float4 *>(a.models + 16 * (size_t)i);
     for (int c = 0; c < 4; ++c) {
         const float4 v = src[c];
         M.m[4 * c] = v.x; M.m[4 * c + 1] = v.y; M.m[4 * c + 2] = v.z; M.m[4 * c + 3] = v.w;
     }
-    const Mat4 R = mul(pv, M);
-    float4 *dst = reinterpret_cast<float4 *>(pvm + 16 * (size_t)i);
+    const Mat4 R = mul(a.pv, M);
+    float4 *dst = reinterpret_cast<float4 *>(a.pvm + 16 * (size_t)i);
     for (int c = 0; c < 4; ++c) dst[c] = make_float4(R.m[4 * c], R.m[4 * c + 1], R.m[4 * c + 2], R.m[4 * c + 3]);
+
+    const MeshDev mesh = a.meshes[a.object_mesh[i]];
+    const float ax = fmaxf(fabsf(mesh.lo[0]), fabsf(mesh.hi[0]));
+    const float ay = fmaxf(fabsf(mesh.lo[1]), fabsf(mesh.hi[1]));
+    const float az = fmaxf(fabsf(mesh.lo[2]), fabsf(mesh.hi[2]));
+    float S[4]; // magnitude of the terms summed into each clip coordinate
+    for (int r = 0; r < 4; ++r)
+        S[r] = fabsf(R.m[r]) * ax + fabsf(R.m[4 + r]) * ay + fabsf(R.m[8 + r]) * az + fabsf(R.m[12 + r]);
+    const float eps = 9.5367431640625e-7f; // 2^-20: sixteen times the unit roundoff
+    const float m_near = S[2] * eps, m_far = (S[3] + S[2]) * eps, m_x = (S[3] + S[0]) * eps, m_y = (S[3] + S[1]) * eps;
+    int out[6] = {0, 0, 0, 0, 0, 0};
+    float ys_min = __builtin_inff(), ys_max = -__builtin_inff();
+    bool w_pos = true;
+    for (int k = 0; k < 8; ++k) {
+        const float4 c = transform_vertex(R.m, (k & 1) ? mesh.hi[0] : mesh.lo[0], (k & 2) ? mesh.hi[1] : mesh.lo[1],
+                                          (k & 4) ? mesh.hi[2] : mesh.lo[2]);
+        out[0] += (c.z < -m_near);
+        out[1] += (c.w - c.z < -m_far);
+        out[2] += (c.w + c.x < -m_x);
+        out[3] += (c.w - c.x < -m_x);
+        out[4] += (c.w + c.y < -m_y);
+        out[5] += (c.w - c.y < -m_y);
+        w_pos = w_pos && (c.w > S[3] * eps) && (c.w > 1.0e-20f);
+        const float ys = (c.y / c.w + 1.0f) * a.g.half_h;
+        ys_min = fminf(ys_min, ys);
+        ys_max = fmaxf(ys_max, ys);
+    }
+    bool vis = true;
+    for (int p = 0; p < 6; ++p) vis = vis && out[p] != 8;
+    // scissor rows: only when every corner is in front of the eye (then the projection is bounded)
+    if (w_pos && (ys_max < (float)a.g.sy0 - 2.0f || ys_min > (float)a.g.sy1 + 2.0f)) vis = false;
+    if (mesh.n_tri == 0) vis = false;
+    a.visible[i] = vis ? 1 : 0;
 }
 
 __device__ inline void store_model(float *models, uint32_t i, const Mat4 &R)
@@ -98,17 +151,6 @@ __global__ void k_rotation_system(sxe_transform *__restrict__ t, float *__restri
 // Vertex stage
 // ------------------------------------------------------------------------------------------
 
-// gl_Position = PVM * (pos, 1) with each row summed left to right (standard.vert:28).
-__device__ inline float4 transform_vertex(const float *__restrict__ pvm, float x, float y, float z)
-{
-    float4 r;
-    r.x = ((pvm[0] * x + pvm[4] * y) + pvm[8] * z) + pvm[12];
-    r.y = ((pvm[1] * x + pvm[5] * y) + pvm[9] * z) + pvm[13];
-    r.z = ((pvm[2] * x + pvm[6] * y) + pvm[10] * z) + pvm[14];
-    r.w = ((pvm[3] * x + pvm[7] * y) + pvm[11] * z) + pvm[15];
-    return r;
-}
-
 // Stand-alone vertex kernel over SoA position streams: each lane reads four consecutive vertices
 // with three 128-bit loads and writes four clip positions.  The frame pipeline transforms
 // vertices inside k_setup instead (same function); this kernel serves sxe_read_clip_positions.
@@ -130,6 +172,85 @@ __global__ __launch_bounds__(256) void k_vertex(const float *__restrict__ px, co
     float4 *dst = clip + (size_t)vb.clip_base + v0;
     for (int k = 0; k < 4; ++k)
         if (v0 + k < mesh.n_vtx) dst[k] = transform_vertex(pvm, xs[k], ys[k], zs[k]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangle records
+// ------------------------------------------------------------------------------------------
+
+struct Tri { // one screen triangle as the raster and resolve loops use it
+    int32_t x0, y0, x1, y1, x2, y2;
+};
+
+__device__ inline bool fits16(int32_t d) { return d >= -32767 && d <= 32767; }
+
+__device__ inline Tri unpack_tri(const RastRec &r, const WideRec *__restrict__ wide, uint32_t slot)
+{
+    Tri t;
+    t.x0 = r.x0;
+    t.y0 = r.y0;
+    if (r.d1 == kWideTri) {
+        const WideRec w = wide[slot];
+        t.x1 = w.x1; t.y1 = w.y1; t.x2 = w.x2; t.y2 = w.y2;
+    } else {
+        t.x1 = r.x0 + (int32_t)(int16_t)(r.d1 & 0xFFFFu);
+        t.y1 = r.y0 + ((int32_t)r.d1 >> 16);
+        t.x2 = r.x0 + (int32_t)(int16_t)(r.d2 & 0xFFFFu);
+        t.y2 = r.y0 + ((int32_t)r.d2 >> 16);
+    }
+    return t;
+}
+
+// 1 / doubled area, as the setup stage defines it: the reciprocal of the area converted to float.
+__device__ inline float recip_area(const Tri &t)
+{
+    const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
+    return 1.0f / (float)area2;
+}
+
+// Inclusive pixel box of a triangle inside the rectangle [cx0,cx1] x [cy0,cy1].
+// Pixel (i,j) is sampled at (256 i + 128, 256 j + 128).
+__device__ inline bool pixel_box(const Tri &t, int32_t cx0, int32_t cx1, int32_t cy0, int32_t cy1, int32_t &bx0,
+                                 int32_t &bx1, int32_t &by0, int32_t &by1)
+{
+    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
+    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
+    bx0 = max((xmin + 127) >> 8, cx0);
+    bx1 = min((xmax - 128) >> 8, cx1);
+    by0 = max((ymin + 127) >> 8, cy0);
+    by1 = min((ymax - 128) >> 8, cy1);
+    return bx0 <= bx1 && by0 <= by1;
+}
+
+// True when every edge-function value at a pixel of the triangle's own box fits 32 bits.
+__device__ inline bool narrow(const Tri &t)
+{
+    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
+    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
+    return (xmax - xmin) < 16384 && (ymax - ymin) < 16384;
+}
+
+// Top-left rule as a bias: an edge function of exactly 0 counts only on top or left edges, so
+// "inside" is E - bias >= 0 with bias 0 on those edges and 1 on the others.
+__device__ inline int32_t edge_bias(int32_t ex, int32_t ey) { return (ey < 0 || (ey == 0 && ex > 0)) ? 0 : 1; }
+
+// Does a narrow triangle cover at least one sample of its (small) pixel box?
+__device__ inline bool covers_any(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
+{
+    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
+    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
+    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+    const int32_t b0 = edge_bias(ex0, ey0), b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+    bool any = false;
+    for (int32_t j = by0; j <= by1; ++j)
+        for (int32_t i = bx0; i <= bx1; ++i) {
+            const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
+            const int32_t E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - b0;
+            const int32_t E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
+            const int32_t E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
+            any = any || ((E0 | E1 | E2) >= 0);
+        }
+    return any;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -185,17 +306,16 @@ __device__ int clip_polygon(ClipVert *poly, ClipVert *tmp, int n)
 }
 
 struct ScreenTri {
-    int32_t X0, Y0, X1, Y1, X2, Y2; // 24.8 fixed point, oriented so that the doubled area is > 0
-    int32_t px0, px1, py0, py1;     // inclusive pixel bounding box, clamped to the scissor
-    float zn0, zn1, zn2;            // z/w per corner (after reorientation)
-    float rw0, rw1, rw2;            // 1/w per corner
-    float rA;                       // 1 / doubled area
-    bool swapped;                   // corners 1 and 2 were exchanged
+    Tri t;                      // oriented so that the doubled area is > 0
+    int32_t px0, px1, py0, py1; // inclusive pixel box, clamped to the frame and the scissor rows
+    float zn0, zn1, zn2;        // z/w per corner (after reorientation)
+    float rw0, rw1, rw2;        // 1/w per corner
+    bool swapped;               // corners 1 and 2 were exchanged
 };
 
 // Perspective divide, viewport map, snap, orientation, bounding box.  False = nothing to draw.
-__device__ inline bool setup_screen_tri(const float4 &c0, const float4 &c1, const float4 &c2,
-                                        const FrameGeom &g, ScreenTri &s)
+__device__ inline bool setup_screen_tri(const float4 &c0, const float4 &c1, const float4 &c2, const FrameGeom &g,
+                                        ScreenTri &s)
 {
     if (!(c0.w > 0.0f) || !(c1.w > 0.0f) || !(c2.w > 0.0f)) return false;
     const float rw0 = 1.0f / c0.w, rw1 = 1.0f / c1.w, rw2 = 1.0f / c2.w;
@@ -206,63 +326,54 @@ __device__ inline bool setup_screen_tri(const float4 &c0, const float4 &c1, cons
     if (!(fabsf(xs0) <= lim) || !(fabsf(ys0) <= lim) || !(fabsf(xs1) <= lim) || !(fabsf(ys1) <= lim) ||
         !(fabsf(xs2) <= lim) || !(fabsf(ys2) <= lim))
         return false;
-    const int32_t X0 = (int32_t)rintf(xs0), Y0 = (int32_t)rintf(ys0);
-    int32_t X1 = (int32_t)rintf(xs1), Y1 = (int32_t)rintf(ys1);
-    int32_t X2 = (int32_t)rintf(xs2), Y2 = (int32_t)rintf(ys2);
-    long long area2 = (long long)(X1 - X0) * (long long)(Y2 - Y0) - (long long)(X2 - X0) * (long long)(Y1 - Y0);
+    Tri t;
+    t.x0 = (int32_t)rintf(xs0); t.y0 = (int32_t)rintf(ys0);
+    t.x1 = (int32_t)rintf(xs1); t.y1 = (int32_t)rintf(ys1);
+    t.x2 = (int32_t)rintf(xs2); t.y2 = (int32_t)rintf(ys2);
+    const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
     if (area2 == 0) return false;
     float zn1 = c1.z * rw1, zn2 = c2.z * rw2, r1 = rw1, r2 = rw2;
     s.swapped = area2 < 0;
-    if (s.swapped) {
-        int32_t t;
-        t = X1; X1 = X2; X2 = t;
-        t = Y1; Y1 = Y2; Y2 = t;
+    if (s.swapped) { // no face culling (Rasterizer::FILL): reorient instead
+        int32_t q;
+        q = t.x1; t.x1 = t.x2; t.x2 = q;
+        q = t.y1; t.y1 = t.y2; t.y2 = q;
         float f;
         f = zn1; zn1 = zn2; zn2 = f;
         f = r1; r1 = r2; r2 = f;
-        area2 = -area2;
     }
-    const int32_t xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
-    const int32_t ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-    // pixel (i,j) is sampled at (256 i + 128, 256 j + 128)
-    int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
-    int32_t py0 = (ymin + 127) >> 8, py1 = (ymax - 128) >> 8;
-    px0 = max(px0, 0);
-    px1 = min(px1, (int32_t)g.width - 1);
-    py0 = max(py0, (int32_t)g.sy0);
-    py1 = min(py1, (int32_t)g.sy1 - 1);
-    if (px0 > px1 || py0 > py1) return false;
-    s.X0 = X0; s.Y0 = Y0; s.X1 = X1; s.Y1 = Y1; s.X2 = X2; s.Y2 = Y2;
-    s.px0 = px0; s.px1 = px1; s.py0 = py0; s.py1 = py1;
+    if (!pixel_box(t, 0, (int32_t)g.width - 1, (int32_t)g.sy0, (int32_t)g.sy1 - 1, s.px0, s.px1, s.py0, s.py1)) return false;
+    s.t = t;
     s.zn0 = c0.z * rw0; s.zn1 = zn1; s.zn2 = zn2;
     s.rw0 = rw0; s.rw1 = r1; s.rw2 = r2;
-    s.rA = 1.0f / (float)area2;
     return true;
-}
-
-__device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
-{
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(v, d);
-        if (lane >= d) v += y;
-    }
-    return v;
 }
 
 struct Attr3 {
     float a0, a1, a2;
 };
 
-// Writes the record of one screen triangle.  uv / rgb are per-corner attributes in the original
-// corner order; corner 1 and 2 are exchanged when the triangle was reoriented.
-__device__ inline void write_records(const SetupArgs &a, uint32_t slot, const ScreenTri &s, uint32_t prim,
+// Writes the records of one screen triangle into slot `rec`.  uv / rgb are per-corner attributes
+// in the original corner order; corners 1 and 2 are exchanged when the triangle was reoriented.
+__device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
                                      int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
 {
     RastRec r;
-    r.x0 = s.X0; r.y0 = s.Y0; r.x1 = s.X1; r.y1 = s.Y1; r.x2 = s.X2; r.y2 = s.Y2;
-    r.z0 = s.zn0; r.dz1 = s.zn1 - s.zn0; r.dz2 = s.zn2 - s.zn0; r.rA = s.rA;
-    r.prim = prim; r.texture = texture;
-    a.rast[slot] = r;
+    r.x0 = s.t.x0; r.y0 = s.t.y0;
+    const int32_t dx1 = s.t.x1 - s.t.x0, dy1 = s.t.y1 - s.t.y0, dx2 = s.t.x2 - s.t.x0, dy2 = s.t.y2 - s.t.y0;
+    if (fits16(dx1) && fits16(dy1) && fits16(dx2) && fits16(dy2)) {
+        r.d1 = ((uint32_t)dx1 & 0xFFFFu) | ((uint32_t)dy1 << 16);
+        r.d2 = ((uint32_t)dx2 & 0xFFFFu) | ((uint32_t)dy2 << 16);
+    } else {
+        r.d1 = kWideTri;
+        r.d2 = 0;
+        WideRec w;
+        w.x1 = s.t.x1; w.y1 = s.t.y1; w.x2 = s.t.x2; w.y2 = s.t.y2;
+        a.wide[rec] = w;
+    }
+    r.z0 = s.zn0; r.dz1 = s.zn1 - s.zn0; r.dz2 = s.zn2 - s.zn0;
+    r.order = order;
+    a.rast[rec] = r;
     if (s.swapped) {
         float t;
         t = u.a1; u.a1 = u.a2; u.a2 = t;
@@ -271,22 +382,20 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t slot, const Sc
         t = cg.a1; cg.a1 = cg.a2; cg.a2 = t;
         t = cb.a1; cb.a1 = cb.a2; cb.a2 = t;
     }
+    ShadeRec h;
+    h.iw0 = s.rw0; h.diw1 = s.rw1 - s.rw0; h.diw2 = s.rw2 - s.rw0;
     if (a.shading != SXE_SHADE_VERTEX_COLOR) {
         const float uw0 = u.a0 * s.rw0, uw1 = u.a1 * s.rw1, uw2 = u.a2 * s.rw2;
         const float vw0 = v.a0 * s.rw0, vw1 = v.a1 * s.rw1, vw2 = v.a2 * s.rw2;
-        ShadeRec h;
-        h.iw0 = s.rw0; h.diw1 = s.rw1 - s.rw0; h.diw2 = s.rw2 - s.rw0;
         h.uw0 = uw0; h.duw1 = uw1 - uw0; h.duw2 = uw2 - uw0;
         h.vw0 = vw0; h.dvw1 = vw1 - vw0; h.dvw2 = vw2 - vw0;
-        h.pad0 = h.pad1 = h.pad2 = 0.0f;
-        a.shade[slot] = h;
     } else {
-        ShadeRec h;
-        h.iw0 = s.rw0; h.diw1 = s.rw1 - s.rw0; h.diw2 = s.rw2 - s.rw0;
         h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
-        h.pad0 = h.pad1 = h.pad2 = 0.0f;
-        a.shade[slot] = h;
     }
+    h.prim = prim;
+    h.fan_base = 0;
+    h.tex_fan = (uint32_t)texture & 0xFFFFFFu;
+    a.shade[rec] = h;
     if (a.shading != SXE_SHADE_TEXTURE) {
         const float r0 = cr.a0 * s.rw0, r1 = cr.a1 * s.rw1, r2 = cr.a2 * s.rw2;
         const float g0 = cg.a0 * s.rw0, g1 = cg.a1 * s.rw1, g2 = cg.a2 * s.rw2;
@@ -296,40 +405,33 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t slot, const Sc
         c.gw0 = g0; c.dgw1 = g1 - g0; c.dgw2 = g2 - g0;
         c.bw0 = b0; c.dbw1 = b1 - b0; c.dbw2 = b2 - b0;
         c.pad0 = c.pad1 = c.pad2 = 0.0f;
-        a.color[slot] = c;
+        a.color[rec] = c;
     }
 }
 
-// Bin a triangle whose pixel box spans several tiles (or comes from the clipper): one atomic per tile.
-template <bool EMIT>
-__device__ inline void bin_box(const SetupArgs &a, const ScreenTri &s, uint32_t slot)
+// One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
+__device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
 {
     const int32_t tx0 = s.px0 / kTile, tx1 = s.px1 / kTile;
     const int32_t ty0 = s.py0 / kTile - (int32_t)a.g.tile_row0, ty1 = s.py1 / kTile - (int32_t)a.g.tile_row0;
     for (int32_t ty = ty0; ty <= ty1; ++ty)
-        for (int32_t tx = tx0; tx <= tx1; ++tx) {
-            const uint32_t tile = (uint32_t)ty * a.g.tiles_x + (uint32_t)tx;
-            if (EMIT) {
-                const uint32_t pos = atomicAdd(&a.tile_fill[tile], 1u);
-                a.bins[a.tile_off[tile] + pos] = slot;
-            } else {
-                atomicAdd(&a.tile_count[tile], 1u);
-            }
-        }
+        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&a.tile_count[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx], 1u);
 }
 
-// One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object,
-// so record slots (workgroup base + rank inside the workgroup) follow submission order, which is
-// what makes "first primitive wins a depth tie" fall out of a (depth|slot) minimum.
-template <bool EMIT>
+// One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object
+// and owns 256 consecutive record slots, which it fills from the front in submission order.  That
+// order is what makes "first primitive wins a depth tie" (Comparison::Less,
+// src/renderer/drawer.rs:700) fall out of a (depth | slot) minimum.
 __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
 {
     __shared__ uint32_t s_wave_tot[kSetupThreads / 64];
-    if (EMIT && a.counters->overflow) return;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const BlockDesc bd = a.blocks[blockIdx.x];
     const InstDev inst = a.insts[bd.inst];
+    if (!a.visible[inst.object]) {
+        if (tid == 0) a.blk_count[blockIdx.x] = 0;
+        return;
+    }
     const MeshDev mesh = a.meshes[inst.mesh];
     const float *pvm = a.pvm + 16 * (size_t)inst.object;
     const uint32_t t = bd.tri_start + tid;
@@ -338,10 +440,8 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
     enum { CULLED = 0, FAST = 1, CLIP = 2 };
     int state = CULLED;
     uint32_t vi0 = 0, vi1 = 0, vi2 = 0;
-    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0;
     ScreenTri st;
     st.px0 = st.px1 = st.py0 = st.py1 = 0;
-    uint32_t n_out = 0;
 
     if (valid) {
         const uint32_t *ip = a.indices + mesh.idx_base + 3 * (size_t)t;
@@ -349,9 +449,9 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
         vi1 = mesh.vtx_base + ip[1];
         vi2 = mesh.vtx_base + ip[2];
         const float *p0 = a.vertices[vi0].pos, *p1 = a.vertices[vi1].pos, *p2 = a.vertices[vi2].pos;
-        c0 = transform_vertex(pvm, p0[0], p0[1], p0[2]);
-        c1 = transform_vertex(pvm, p1[0], p1[1], p1[2]);
-        c2 = transform_vertex(pvm, p2[0], p2[1], p2[2]);
+        const float4 c0 = transform_vertex(pvm, p0[0], p0[1], p0[2]);
+        const float4 c1 = transform_vertex(pvm, p1[0], p1[1], p1[2]);
+        const float4 c2 = transform_vertex(pvm, p2[0], p2[1], p2[2]);
         // all three corners outside one plane of the view volume -> nothing visible
         const bool rej =
             (!(c0.z >= 0.0f) && !(c1.z >= 0.0f) && !(c2.z >= 0.0f)) ||
@@ -371,28 +471,20 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
             if (inside) {
                 if (setup_screen_tri(c0, c1, c2, a.g, st)) {
                     state = FAST;
-                    n_out = 1;
+                    // a triangle whose box holds a few pixels and contains none of their samples draws nothing
+                    const int32_t bw = st.px1 - st.px0 + 1, bh = st.py1 - st.py0 + 1;
+                    if (bw * bh <= 4 && narrow(st.t) && !covers_any(st.t, st.px0, st.px1, st.py0, st.py1)) state = CULLED;
                 }
             } else {
-                // reserve one slot per fan triangle of the clipped polygon
-                ClipVert poly[10], tmp[10];
-                const float4 cs2[3] = {c0, c1, c2};
-                for (int k = 0; k < 3; ++k) {
-                    poly[k].c[0] = cs2[k].x; poly[k].c[1] = cs2[k].y; poly[k].c[2] = cs2[k].z; poly[k].c[3] = cs2[k].w;
-                    for (int q = 4; q < 9; ++q) poly[k].c[q] = 0.0f;
-                }
-                const int n = clip_polygon(poly, tmp, 3);
-                if (n >= 3) {
-                    state = CLIP;
-                    n_out = (uint32_t)(n - 2);
-                }
+                state = CLIP; // crosses the near, far or a guard-band plane: k_clip cuts it
             }
         }
     }
 
-    // workgroup exclusive scan of n_out
-    const uint32_t incl = wave_inclusive_scan(n_out, lane);
-    if (lane == 63) s_wave_tot[wave] = incl;
+    // rank of every survivor inside the workgroup
+    const unsigned long long alive = __ballot(state != CULLED);
+    const uint32_t wave_rank = (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_tot[wave] = (uint32_t)__popcll(alive);
     __syncthreads();
     uint32_t wave_base = 0, total = 0;
     for (int w = 0; w < kSetupThreads / 64; ++w) {
@@ -400,16 +492,12 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
         if (w < wave) wave_base += v;
         total += v;
     }
-    const uint32_t rank = wave_base + incl - n_out;
-    uint32_t slot = rank;
-    if (EMIT) {
-        slot += a.blk_base[blockIdx.x];
-    } else if (tid == 0) {
-        a.blk_count[blockIdx.x] = total;
-    }
+    if (tid == 0) a.blk_count[blockIdx.x] = total;
+    const uint32_t slot = blockIdx.x * kSetupThreads + wave_base + wave_rank;
+    const uint32_t prim = inst.prim_base + t;
 
     // ---- triangles that needed no clipping ----
-    if (EMIT && state == FAST) {
+    if (state == FAST) {
         const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
         Attr3 u = {w0.uv[0], w1.uv[0], w2.uv[0]}, v = {w0.uv[1], w1.uv[1], w2.uv[1]};
         Attr3 cr = {0, 0, 0}, cg = {0, 0, 0}, cb = {0, 0, 0};
@@ -418,84 +506,135 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
             cg = {w0.color[1], w1.color[1], w2.color[1]};
             cb = {w0.color[2], w1.color[2], w2.color[2]};
         }
-        write_records(a, slot, st, inst.prim_base + t, inst.texture, u, v, cr, cg, cb);
+        write_records(a, slot, slot, st, prim, inst.texture, u, v, cr, cg, cb);
     }
     const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
     const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
     const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
-    // wave-aggregated bin allocation: one atomic per distinct tile per wave
+    // wave-aggregated tile counting: one atomic per distinct tile per wave
     unsigned long long pending = __ballot(single);
     while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const uint32_t lt = __shfl(tile, leader);
-        const bool mine = single && tile == lt;
-        const unsigned long long same = __ballot(mine);
-        uint32_t base = 0;
-        if (lane == leader) {
-            const uint32_t cnt = (uint32_t)__popcll(same);
-            base = EMIT ? atomicAdd(&a.tile_fill[lt], cnt) : atomicAdd(&a.tile_count[lt], cnt);
-        }
-        if (EMIT) {
-            base = __shfl(base, leader);
-            if (mine) {
-                const uint32_t r = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                a.bins[a.tile_off[lt] + base + r] = slot;
-            }
-        }
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+        const uint32_t lt = __builtin_amdgcn_readlane(tile, leader);
+        const unsigned long long same = __ballot(single && tile == lt);
+        if (lane == leader) atomicAdd(&a.tile_count[lt], (uint32_t)__popcll(same));
         pending &= ~same;
     }
-    if (state == FAST && !single) bin_box<EMIT>(a, st, slot);
+    if (state == FAST && !single) count_box(a, st);
 
-    // ---- triangles cut by the near/far/guard planes: fan of the clipped polygon ----
+    // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
+    // order) and are queued for k_clip ----
     if (state == CLIP) {
-        ClipVert poly[10], tmp[10];
-        const float4 cs[3] = {c0, c1, c2};
-        const uint32_t vis[3] = {vi0, vi1, vi2};
-        for (int k = 0; k < 3; ++k) {
-            const sxe_vertex &w = a.vertices[vis[k]];
-            poly[k].c[0] = cs[k].x; poly[k].c[1] = cs[k].y; poly[k].c[2] = cs[k].z; poly[k].c[3] = cs[k].w;
-            poly[k].c[4] = w.uv[0]; poly[k].c[5] = w.uv[1];
-            poly[k].c[6] = w.color[0]; poly[k].c[7] = w.color[1]; poly[k].c[8] = w.color[2];
-        }
-        const int n = clip_polygon(poly, tmp, 3);
-        for (int f = 1; f + 1 < n; ++f) {
-            const ClipVert &q0 = poly[0], &q1 = poly[f], &q2 = poly[f + 1];
-            ScreenTri s2;
-            if (!setup_screen_tri(make_float4(q0.c[0], q0.c[1], q0.c[2], q0.c[3]),
-                                  make_float4(q1.c[0], q1.c[1], q1.c[2], q1.c[3]),
-                                  make_float4(q2.c[0], q2.c[1], q2.c[2], q2.c[3]), a.g, s2))
-                continue;
-            const uint32_t sl = slot + (uint32_t)(f - 1);
-            if (EMIT) {
-                Attr3 u = {q0.c[4], q1.c[4], q2.c[4]}, v = {q0.c[5], q1.c[5], q2.c[5]};
-                Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
-                write_records(a, sl, s2, inst.prim_base + t, inst.texture, u, v, cr, cg, cb);
-            }
-            bin_box<EMIT>(a, s2, sl);
+        RastRec none;
+        none.x0 = kNoRaster; none.y0 = 0; none.d1 = 0; none.d2 = 0; none.z0 = none.dz1 = none.dz2 = 0.0f; none.order = slot;
+        a.rast[slot] = none;
+        const uint32_t at = atomicAdd(&a.counters->clip_count, 1u);
+        if (at < a.fan_capacity) {
+            ClipItem it;
+            it.inst = bd.inst; it.tri = t; it.slot = slot;
+            a.clip_list[at] = it;
+        } else {
+            atomicOr(&a.counters->overflow, kOverflowClip);
         }
     }
 }
 
+// One thread per queued triangle: Sutherland-Hodgman, then the fan of the clipped polygon goes to
+// the extra record region; the triangle's own slot only ranks it and points at the fan.
+__global__ __launch_bounds__(64) void k_clip(SetupArgs a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = min(a.counters->clip_count, a.fan_capacity);
+    if (idx >= n) return;
+    const ClipItem it = a.clip_list[idx];
+    const InstDev inst = a.insts[it.inst];
+    const MeshDev mesh = a.meshes[inst.mesh];
+    const float *pvm = a.pvm + 16 * (size_t)inst.object;
+    const uint32_t *ip = a.indices + mesh.idx_base + 3 * (size_t)it.tri;
+    const uint32_t slot = it.slot, prim = inst.prim_base + it.tri;
+    ClipVert poly[10], tmp[10];
+    for (int k = 0; k < 3; ++k) {
+        const sxe_vertex &w = a.vertices[mesh.vtx_base + ip[k]];
+        const float4 c = transform_vertex(pvm, w.pos[0], w.pos[1], w.pos[2]);
+        poly[k].c[0] = c.x; poly[k].c[1] = c.y; poly[k].c[2] = c.z; poly[k].c[3] = c.w;
+        poly[k].c[4] = w.uv[0]; poly[k].c[5] = w.uv[1];
+        poly[k].c[6] = w.color[0]; poly[k].c[7] = w.color[1]; poly[k].c[8] = w.color[2];
+    }
+    const int n_poly = clip_polygon(poly, tmp, 3);
+    const uint32_t n_fan = n_poly >= 3 ? (uint32_t)(n_poly - 2) : 0u;
+    const uint32_t fan0 = n_fan ? atomicAdd(&a.counters->fan_records, n_fan) : 0u;
+    const bool room = fan0 + n_fan <= a.fan_capacity;
+    ShadeRec h;
+    h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
+    h.prim = prim;
+    h.fan_base = a.n_blocks * kSetupThreads + fan0;
+    h.tex_fan = ((uint32_t)inst.texture & 0xFFFFFFu) | ((room ? n_fan : 0u) << 24);
+    a.shade[slot] = h;
+    if (!room) {
+        atomicOr(&a.counters->overflow, kOverflowClip);
+        return;
+    }
+    RastRec none;
+    none.x0 = kNoRaster; none.y0 = 0; none.d1 = 0; none.d2 = 0; none.z0 = none.dz1 = none.dz2 = 0.0f; none.order = slot;
+    for (uint32_t f = 0; f < n_fan; ++f) {
+        const ClipVert &q0 = poly[0], &q1 = poly[f + 1], &q2 = poly[f + 2];
+        const uint32_t rec = h.fan_base + f;
+        ScreenTri s2;
+        if (!setup_screen_tri(make_float4(q0.c[0], q0.c[1], q0.c[2], q0.c[3]), make_float4(q1.c[0], q1.c[1], q1.c[2], q1.c[3]),
+                              make_float4(q2.c[0], q2.c[1], q2.c[2], q2.c[3]), a.g, s2)) {
+            a.rast[rec] = none;
+            continue;
+        }
+        Attr3 u = {q0.c[4], q1.c[4], q2.c[4]}, v = {q0.c[5], q1.c[5], q2.c[5]};
+        Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
+        write_records(a, rec, slot, s2, prim, inst.texture, u, v, cr, cg, cb);
+        count_box(a, s2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
-// Scans
+// Scan
 // ------------------------------------------------------------------------------------------
 
-// Workgroup 0 scans the per-workgroup record counts, workgroup 1 the per-tile bin counts.
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
+// Workgroup 0: exclusive scan of the per-tile bin counts (eight counts per thread and round).
+// Workgroup 1: total number of surviving triangles.
 __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 {
     __shared__ uint32_t s_part[16];
     __shared__ uint32_t s_carry;
-    const bool tiles = blockIdx.x == 1;
-    const uint32_t *src = tiles ? a.tile_count : a.blk_count;
-    uint32_t *dst = tiles ? a.tile_off : a.blk_base;
-    const uint32_t n = tiles ? a.n_tiles : a.n_blocks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 1) {
+        uint32_t sum = 0;
+        for (uint32_t i = tid; i < a.n_blocks; i += 1024) sum += a.blk_count[i];
+        for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) s_part[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; ++w) tot += s_part[w];
+            a.counters->total_records = tot;
+        }
+        return;
+    }
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? src[i] : 0u;
-        const uint32_t incl = wave_inclusive_scan(v, lane);
+    for (uint32_t base = 0; base < a.n_tiles; base += 8192) {
+        const uint32_t i0 = base + 8u * (uint32_t)tid;
+        uint32_t v[8], sum = 0;
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (i0 + k < a.n_tiles) ? a.tile_count[i0 + k] : 0u;
+            sum += v[k];
+        }
+        const uint32_t incl = wave_inclusive_scan(sum, lane);
         if (lane == 63) s_part[wave] = incl;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
@@ -505,20 +644,103 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
             tot += p;
         }
         const uint32_t carry = s_carry;
-        if (i < n) dst[i] = carry + wbase + incl - v;
+        uint32_t run = carry + wbase + incl - sum;
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < a.n_tiles) a.tile_off[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
         if (tid == 0) s_carry = carry + tot;
         __syncthreads();
     }
     if (tid == 0) {
         const uint32_t total = s_carry;
-        if (tiles) {
-            a.counters->total_pairs = total;
-            if (total > a.bin_capacity) atomicOr(&a.counters->overflow, 2u);
-        } else {
-            a.counters->total_records = total;
-            if (total > a.rec_capacity) atomicOr(&a.counters->overflow, 1u);
+        a.counters->total_pairs = total;
+        if (total > a.bin_capacity) atomicOr(&a.counters->overflow, kOverflowBins);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Binning
+// ------------------------------------------------------------------------------------------
+
+// Reads the surviving records back and scatters their slot numbers into the tile bins.  Entries
+// whose pixel box inside the tile holds at most kSmallBox pixels are stored from the front of the
+// tile's range, the others from its back, so that the raster kernel meets boxes of similar size
+// next to each other.  The order of entries inside a bin is irrelevant to the image.
+__global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
+{
+    if (a.counters->overflow) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t rec;
+    bool valid;
+    if (blockIdx.x < a.n_blocks) {
+        const uint32_t cnt = a.blk_count[blockIdx.x];
+        if (cnt == 0) return;
+        valid = (uint32_t)tid < cnt;
+        rec = blockIdx.x * kSetupThreads + tid;
+    } else {
+        const uint32_t first = (blockIdx.x - a.n_blocks) * kSetupThreads;
+        const uint32_t n_fan = a.counters->fan_records;
+        if (first >= n_fan) return;
+        valid = first + tid < n_fan;
+        rec = a.n_blocks * kSetupThreads + first + tid;
+    }
+    Tri t = {0, 0, 0, 0, 0, 0};
+    int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+    if (valid) {
+        const RastRec r = a.rast[rec];
+        valid = r.x0 != kNoRaster;
+        if (valid) {
+            t = unpack_tri(r, a.wide, rec);
+            valid = pixel_box(t, 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1);
         }
+    }
+    const int32_t tx0 = bx0 / kTile, tx1 = bx1 / kTile, ty0 = by0 / kTile, ty1 = by1 / kTile;
+    const bool single = valid && tx0 == tx1 && ty0 == ty1;
+    const bool big = (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox;
+    const uint32_t tile = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+    const uint32_t key = single ? (tile * 2u + (big ? 1u : 0u)) : 0xFFFFFFFFu;
+    // group the lanes of the wave by (tile, class) without touching memory ...
+    unsigned long long pending = __ballot(single);
+    int my_leader = lane;
+    uint32_t my_rank = 0, my_count = 0;
+    while (pending) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+        const uint32_t lk = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = single && key == lk;
+        const unsigned long long same = __ballot(mine);
+        if (mine) {
+            my_leader = leader;
+            my_rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            my_count = (uint32_t)__popcll(same);
+        }
+        pending &= ~same;
+    }
+    // ... then every group leader reserves its run of bin entries in one round of atomics
+    uint32_t base = 0;
+    if (single && lane == my_leader) base = atomicAdd((key & 1u) ? &a.fill_back[tile] : &a.fill_front[tile], my_count);
+    base = __shfl(base, my_leader);
+    if (single) {
+        const uint32_t p = base + my_rank;
+        const uint32_t off = a.tile_off[tile];
+        a.bins[(key & 1u) ? off + a.tile_count[tile] - 1u - p : off + p] = rec;
+    }
+    if (valid && !single) {
+        for (int32_t ty = ty0; ty <= ty1; ++ty)
+            for (int32_t tx = tx0; tx <= tx1; ++tx) {
+                const uint32_t tl = (uint32_t)(ty - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx;
+                const int32_t w = min(bx1, tx * kTile + kTile - 1) - max(bx0, tx * kTile) + 1;
+                const int32_t h = min(by1, ty * kTile + kTile - 1) - max(by0, ty * kTile) + 1;
+                const uint32_t off = a.tile_off[tl];
+                if (w * h > kSmallBox) {
+                    const uint32_t p = atomicAdd(&a.fill_back[tl], 1u);
+                    a.bins[off + a.tile_count[tl] - 1u - p] = rec;
+                } else {
+                    const uint32_t p = atomicAdd(&a.fill_front[tl], 1u);
+                    a.bins[off + p] = rec;
+                }
+            }
     }
 }
 
@@ -583,10 +805,54 @@ __device__ inline float clamp_depth(float z)
     return z;
 }
 
+__device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint32_t order)
+{
+    if (z < 1.0f) { // a depth of 1.0 can never be Less than the cleared 1.0
+        const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | order;
+        unsigned long long *p = &vis[pix];
+        if (key < *p) atomicMin(p, key);
+    }
+}
+
+// One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions.
+__device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
+                                   int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
+{
+    // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
+    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
+    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
+    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+    const float rA = 1.0f / (float)(ex2 * (t.y2 - t.y0) - (t.x2 - t.x0) * ey2);
+    const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
+    int32_t R0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - edge_bias(ex0, ey0);
+    int32_t R1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
+    int32_t R2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
+    const int32_t ax0 = -256 * ey0, ax1 = -256 * ey1, ax2 = -256 * ey2; // one pixel to the right
+    const int32_t ay0 = 256 * ex0, ay1 = 256 * ex1, ay2 = 256 * ex2;    // one pixel down
+    int32_t E0 = R0, E1 = R1, E2 = R2;
+    int32_t i = bx0, j = by0;
+    const int32_t cnt = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    for (int32_t k = 0; k < cnt; ++k) {
+        if ((E0 | E1 | E2) >= 0) {
+            const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
+            const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
+            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, r.order);
+        }
+        E0 += ax0; E1 += ax1; E2 += ax2;
+        if (++i > bx1) {
+            i = bx0;
+            ++j;
+            R0 += ay0; R1 += ay1; R2 += ay2;
+            E0 = R0; E1 = R1; E2 = R2;
+        }
+    }
+}
+
 template <bool COVERAGE>
 __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 {
-    __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | record slot, per pixel
+    __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | order, per pixel
     __shared__ float s_thr[256];
     __shared__ float s_dec[256];
     if (a.counters->overflow) return;
@@ -605,88 +871,88 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
     const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : a.tile_count[tile], off = a.tile_off[tile];
-    for (uint32_t base = (uint32_t)wave * 64u; base < n; base += kRasterThreads) {
-        const uint32_t e = base + (uint32_t)lane;
-        const bool valid = e < n;
-        uint32_t slot = 0;
-        bool small = false, large = false;
-        if (valid) {
-            slot = a.bins[off + e];
-            const RastRec r = a.rast[slot];
-            const int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
-            const int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
-            const int32_t bx0 = max((xmin + 127) >> 8, cx0), bx1 = min((xmax - 128) >> 8, cx1);
-            const int32_t by0 = max((ymin + 127) >> 8, cy0), by1 = min((ymax - 128) >> 8, cy1);
-            const bool nonempty = bx0 <= bx1 && by0 <= by1;
-            const int32_t bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-            small = nonempty && bw * bh <= 16 && (xmax - xmin) < 16384 && (ymax - ymin) < 16384;
-            large = nonempty && !small;
-            if (a.debug & kDebugSkipSmall) small = false;
-            if (a.debug & kDebugSkipLarge) large = false;
-            if (small) {
-                // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
-                const int32_t ex0 = r.x2 - r.x1, ey0 = r.y2 - r.y1;
-                const int32_t ex1 = r.x0 - r.x2, ey1 = r.y0 - r.y2;
-                const int32_t ex2 = r.x1 - r.x0, ey2 = r.y1 - r.y0;
-                // top-left rule: an edge function of exactly 0 counts only on top or left edges
-                const int32_t b0 = (ey0 < 0 || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
-                const int32_t b1 = (ey1 < 0 || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
-                const int32_t b2 = (ey2 < 0 || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
-                int32_t i = bx0, j = by0;
-                const int32_t cnt = bw * bh;
-                for (int32_t k = 0; k < cnt; ++k) {
-                    const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
-                    const int32_t E0 = ex0 * (sy - r.y1) - ey0 * (sx - r.x1);
-                    const int32_t E1 = ex1 * (sy - r.y2) - ey1 * (sx - r.x2);
-                    const int32_t E2 = ex2 * (sy - r.y0) - ey2 * (sx - r.x0);
-                    if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
-                        const float l1 = (float)E1 * r.rA, l2 = (float)E2 * r.rA;
-                        const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-                        if (z < 1.0f) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | slot;
-                            unsigned long long *p = &vis[(j - tpy) * kTile + (i - tpx)];
-                            if (!(a.debug & kDebugSkipAtomic) && key < *p) atomicMin(p, key);
+    const uint32_t n_front = min(a.fill_front[tile], n);
+    // two passes over the bin: the front part holds small boxes, the back part the others
+    for (int part = 0; part < 2; ++part) {
+        const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
+        for (uint32_t base = lo + (uint32_t)wave * 64u; base < hi; base += kRasterThreads) {
+            const uint32_t e = base + (uint32_t)lane;
+            const bool valid = e < hi;
+            bool wide_box = false;
+            RastRec r;
+            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
+            Tri t = {0, 0, 0, 0, 0, 0};
+            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            if (valid) {
+                const uint32_t slot = a.bins[off + e];
+                r = a.rast[slot];
+                t = unpack_tri(r, a.wide, slot);
+                const bool nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
+                const bool alone = nonempty && (bx1 - bx0 + 1) * (by1 - by0 + 1) <= kLaneBox && narrow(t);
+                wide_box = nonempty && !alone;
+                if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, bx0, bx1, by0, by1, tpx, tpy);
+            }
+            // boxes too large for one lane: the whole wave walks the box, 64 pixels per step
+            unsigned long long lm = (a.debug & kDebugSkipLarge) ? 0ull : __ballot(wide_box);
+            while (lm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                lm &= lm - 1;
+                Tri q;
+                q.x0 = __builtin_amdgcn_readlane(t.x0, src); q.y0 = __builtin_amdgcn_readlane(t.y0, src);
+                q.x1 = __builtin_amdgcn_readlane(t.x1, src); q.y1 = __builtin_amdgcn_readlane(t.y1, src);
+                q.x2 = __builtin_amdgcn_readlane(t.x2, src); q.y2 = __builtin_amdgcn_readlane(t.y2, src);
+                const float z0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.z0), src));
+                const float dz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.dz1), src));
+                const float dz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.dz2), src));
+                const uint32_t order = __builtin_amdgcn_readlane(r.order, src);
+                const int32_t qx0 = __builtin_amdgcn_readlane(bx0, src), qx1 = __builtin_amdgcn_readlane(bx1, src);
+                const int32_t qy0 = __builtin_amdgcn_readlane(by0, src), qy1 = __builtin_amdgcn_readlane(by1, src);
+                const float rA = recip_area(q);
+                const uint32_t bw = (uint32_t)(qx1 - qx0 + 1), cnt = bw * (uint32_t)(qy1 - qy0 + 1);
+                const uint32_t magic = (65536u + bw - 1u) / bw; // idx / bw == (idx * magic) >> 16 for idx < 1024, bw <= 32
+                if (narrow(q)) {
+                    // edge functions at the box origin (wave-uniform), then two multiply-adds per lane and edge
+                    const int32_t ex0 = q.x2 - q.x1, ey0 = q.y2 - q.y1;
+                    const int32_t ex1 = q.x0 - q.x2, ey1 = q.y0 - q.y2;
+                    const int32_t ex2 = q.x1 - q.x0, ey2 = q.y1 - q.y0;
+                    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+                    const int32_t sx = 256 * qx0 + 128, sy = 256 * qy0 + 128;
+                    const int32_t R0 = ex0 * (sy - q.y1) - ey0 * (sx - q.x1) - edge_bias(ex0, ey0);
+                    const int32_t R1 = ex1 * (sy - q.y2) - ey1 * (sx - q.x2) - b1;
+                    const int32_t R2 = ex2 * (sy - q.y0) - ey2 * (sx - q.x0) - b2;
+                    for (uint32_t idx = (uint32_t)lane; idx < cnt; idx += 64u) {
+                        const uint32_t row = (idx * magic) >> 16;
+                        const int32_t di = (int32_t)(idx - row * bw), dj = (int32_t)row;
+                        const int32_t E0 = R0 - 256 * ey0 * di + 256 * ex0 * dj;
+                        const int32_t E1 = R1 - 256 * ey1 * di + 256 * ex1 * dj;
+                        const int32_t E2 = R2 - 256 * ey2 * di + 256 * ex2 * dj;
+                        if ((E0 | E1 | E2) >= 0) {
+                            const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
+                            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+                            depth_min(vis, (qy0 + dj - tpy) * kTile + (qx0 + di - tpx), z, order);
                         }
                     }
-                    if (++i > bx1) { i = bx0; ++j; }
+                } else {
+                    const long long ex0 = q.x2 - q.x1, ey0 = q.y2 - q.y1;
+                    const long long ex1 = q.x0 - q.x2, ey1 = q.y0 - q.y2;
+                    const long long ex2 = q.x1 - q.x0, ey2 = q.y1 - q.y0;
+                    const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
+                                    b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
+                    for (uint32_t idx = (uint32_t)lane; idx < cnt; idx += 64u) {
+                        const uint32_t row = (idx * magic) >> 16;
+                        const int32_t i = qx0 + (int32_t)(idx - row * bw), j = qy0 + (int32_t)row;
+                        const long long sx = 256 * i + 128, sy = 256 * j + 128;
+                        const long long E0 = ex0 * (sy - q.y1) - ey0 * (sx - q.x1);
+                        const long long E1 = ex1 * (sy - q.y2) - ey1 * (sx - q.x2);
+                        const long long E2 = ex2 * (sy - q.y0) - ey2 * (sx - q.x0);
+                        if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
+                            const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
+                            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+                            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, order);
+                        }
+                    }
                 }
             }
-        }
-        // triangles with a larger footprint: the whole wave walks the box in 8x8 pixel blocks
-        unsigned long long lm = __ballot(large);
-        while (lm) {
-            const int src = __ffsll((long long)lm) - 1;
-            lm &= lm - 1;
-            const uint32_t sl = __shfl(slot, src);
-            const RastRec r = a.rast[sl];
-            const int32_t xmin = min(r.x0, min(r.x1, r.x2)), xmax = max(r.x0, max(r.x1, r.x2));
-            const int32_t ymin = min(r.y0, min(r.y1, r.y2)), ymax = max(r.y0, max(r.y1, r.y2));
-            const int32_t bx0 = max((xmin + 127) >> 8, cx0), bx1 = min((xmax - 128) >> 8, cx1);
-            const int32_t by0 = max((ymin + 127) >> 8, cy0), by1 = min((ymax - 128) >> 8, cy1);
-            const long long ex0 = r.x2 - r.x1, ey0 = r.y2 - r.y1;
-            const long long ex1 = r.x0 - r.x2, ey1 = r.y0 - r.y2;
-            const long long ex2 = r.x1 - r.x0, ey2 = r.y1 - r.y0;
-            const long long b0 = (ey0 < 0 || (ey0 == 0 && ex0 > 0)) ? 0 : 1;
-            const long long b1 = (ey1 < 0 || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
-            const long long b2 = (ey2 < 0 || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
-            for (int32_t yb = by0; yb <= by1; yb += 8)
-                for (int32_t xb = bx0; xb <= bx1; xb += 8) {
-                    const int32_t i = xb + (lane & 7), j = yb + (lane >> 3);
-                    if (i > bx1 || j > by1) continue;
-                    const long long sx = 256 * i + 128, sy = 256 * j + 128;
-                    const long long E0 = ex0 * (sy - r.y1) - ey0 * (sx - r.x1);
-                    const long long E1 = ex1 * (sy - r.y2) - ey1 * (sx - r.x2);
-                    const long long E2 = ex2 * (sy - r.y0) - ey2 * (sx - r.x0);
-                    if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
-                        const float l1 = (float)E1 * r.rA, l2 = (float)E2 * r.rA;
-                        const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-                        if (z < 1.0f) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | sl;
-                            unsigned long long *p = &vis[(j - tpy) * kTile + (i - tpx)];
-                            if (key < *p) atomicMin(p, key);
-                        }
-                    }
-                }
         }
     }
     __syncthreads();
@@ -704,15 +970,36 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
         uint32_t code = a.clear_code, prim = 0xFFFFFFFFu;
         float depth = 1.0f;
         if (key != kVisEmpty) {
-            const uint32_t slot = (uint32_t)key;
+            uint32_t slot = (uint32_t)key;
             depth = __uint_as_float((uint32_t)(key >> 32));
-            const RastRec r = a.rast[slot];
-            const ShadeRec h = a.shade[slot];
-            prim = r.prim;
+            ShadeRec h = a.shade[slot];
             const long long sx = 256 * i + 128, sy = 256 * j + 128;
-            const long long E1 = (long long)(r.x0 - r.x2) * (sy - r.y2) - (long long)(r.y0 - r.y2) * (sx - r.x2);
-            const long long E2 = (long long)(r.x1 - r.x0) * (sy - r.y0) - (long long)(r.y1 - r.y0) * (sx - r.x0);
-            const float l1 = (float)E1 * r.rA, l2 = (float)E2 * r.rA;
+            const uint32_t n_fan = h.tex_fan >> 24;
+            if (n_fan) {
+                // a clipped triangle won: exactly one triangle of its fan covers this sample
+                const uint32_t fan_base = h.fan_base;
+                for (uint32_t f = 0; f < n_fan; ++f) {
+                    const RastRec fr = a.rast[fan_base + f];
+                    if (fr.x0 == kNoRaster) continue;
+                    const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
+                    const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
+                                    fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
+                    const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
+                    const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
+                    const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
+                    if ((E0 | E1 | E2) >= 0) {
+                        slot = fan_base + f;
+                        break;
+                    }
+                }
+                h = a.shade[slot];
+            }
+            const Tri t = unpack_tri(a.rast[slot], a.wide, slot);
+            prim = h.prim;
+            const float rA = recip_area(t);
+            const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
+            const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
+            const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
             const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
             const float riw = 1.0f / iw;
             float src[4];
@@ -725,7 +1012,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
             } else {
                 const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
                 const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
-                sample_texture(a.texels, a.textures[r.texture], s_dec, u, v, src);
+                sample_texture(a.texels, a.textures[h.tex_fan & 0xFFFFFFu], s_dec, u, v, src);
                 if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
                     const ColorRec c = a.color[slot];
                     src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
@@ -751,10 +1038,10 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 // Launchers
 // ------------------------------------------------------------------------------------------
 
-hipError_t launch_object(const float *models, const Mat4 &pv, float *pvm, uint32_t n, hipStream_t s)
+hipError_t launch_object(const ObjectArgs &a, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_object, dim3((n + 255) / 256), dim3(256), 0, s, models, pv, pvm, n);
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_object, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -781,23 +1068,31 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
     return hipGetLastError();
 }
 
-hipError_t launch_setup_count(const SetupArgs &a, hipStream_t s)
+hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_setup<false>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+    hipLaunchKernelGGL(k_setup, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_setup_emit(const SetupArgs &a, hipStream_t s)
+hipError_t launch_clip(const SetupArgs &a, hipStream_t s)
 {
-    if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_setup<true>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+    // sized for a full clip list; threads beyond the device-side count return at once
+    if (a.n_blocks == 0 || a.fan_capacity == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_clip, dim3((a.fan_capacity + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin(const BinArgs &a, hipStream_t s)
+{
+    if (a.n_blocks + a.fan_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bin, dim3(a.n_blocks + a.fan_blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
