@@ -5,8 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsxe_hip.so")
-SOURCES = ["sxe_api.hip", "sxe_kernels.hip"]
-HEADERS = ["sxe_internal.h", "sxe_math.h", "sxe_srgb_tables.h", os.path.join("..", "..", "include", "sxe.h")]
+SOURCES = ["sxe_api.hip", "sxe_geometry.hip", "sxe_raster.hip"]
+HEADERS = ["sxe_internal.h", "sxe_device.h", "sxe_math.h", "sxe_srgb_tables.h", os.path.join("..", "..", "include", "sxe.h")]
 
 # -ffp-contract=off: the kernels and the host maths must round every operation separately
 # (the parity contract); gfx950 only, no other offload target.

@@ -416,6 +416,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ra.counters = c->counters.p;
     ra.texels = c->texels.p;
     ra.textures = c->textab.p;
+    ra.n_textures = c->n_textures;
     ra.out_color = img.color.p;
     ra.out_depth = img.depth.p;
     ra.out_prim = (c->cfg.flags & SXE_FLAG_WRITE_COVERAGE) ? img.prim.p : nullptr;
@@ -761,6 +762,9 @@ int sxe_sync(sxe_ctx *c)
     c->stats.objects = c->n_objects;
     c->stats.tile_size = kTile;
     c->stats.redraws = c->redraws;
+    if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
+        fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", c->h_counters->pad[0],
+                c->h_counters->pad[1], c->h_counters->pad[2], c->h_counters->clip_count, c->h_counters->fan_records);
     if (c->cfg.flags & SXE_FLAG_TIMING) {
         float ms[EV_N] = {};
         for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i - 1], c->ev[i]));

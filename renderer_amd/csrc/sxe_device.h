@@ -1,0 +1,100 @@
+// sxe_device.h -- device helpers shared by the geometry kernels and the tile kernel: the vertex
+// transform and the screen-triangle record format.
+#pragma once
+
+#include "sxe_internal.h"
+
+namespace sxe {
+
+
+// gl_Position = PVM * (pos, 1) with each row summed left to right (standard.vert:28).
+__device__ inline float4 transform_vertex(const float *__restrict__ pvm, float x, float y, float z)
+{
+    float4 r;
+    r.x = ((pvm[0] * x + pvm[4] * y) + pvm[8] * z) + pvm[12];
+    r.y = ((pvm[1] * x + pvm[5] * y) + pvm[9] * z) + pvm[13];
+    r.z = ((pvm[2] * x + pvm[6] * y) + pvm[10] * z) + pvm[14];
+    r.w = ((pvm[3] * x + pvm[7] * y) + pvm[11] * z) + pvm[15];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangle records
+// ------------------------------------------------------------------------------------------
+
+struct Tri { // one screen triangle as the raster and resolve loops use it
+    int32_t x0, y0, x1, y1, x2, y2;
+};
+
+__device__ inline bool fits16(int32_t d) { return d >= -32767 && d <= 32767; }
+
+__device__ inline Tri unpack_tri(const RastRec &r, const WideRec *__restrict__ wide, uint32_t slot)
+{
+    Tri t;
+    t.x0 = r.x0;
+    t.y0 = r.y0;
+    if (r.d1 == kWideTri) {
+        const WideRec w = wide[slot];
+        t.x1 = w.x1; t.y1 = w.y1; t.x2 = w.x2; t.y2 = w.y2;
+    } else {
+        t.x1 = r.x0 + (int32_t)(int16_t)(r.d1 & 0xFFFFu);
+        t.y1 = r.y0 + ((int32_t)r.d1 >> 16);
+        t.x2 = r.x0 + (int32_t)(int16_t)(r.d2 & 0xFFFFu);
+        t.y2 = r.y0 + ((int32_t)r.d2 >> 16);
+    }
+    return t;
+}
+
+// 1 / doubled area, as the setup stage defines it: the reciprocal of the area converted to float.
+__device__ inline float recip_area(const Tri &t)
+{
+    const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
+    return 1.0f / (float)area2;
+}
+
+// Inclusive pixel box of a triangle inside the rectangle [cx0,cx1] x [cy0,cy1].
+// Pixel (i,j) is sampled at (256 i + 128, 256 j + 128).
+__device__ inline bool pixel_box(const Tri &t, int32_t cx0, int32_t cx1, int32_t cy0, int32_t cy1, int32_t &bx0,
+                                 int32_t &bx1, int32_t &by0, int32_t &by1)
+{
+    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
+    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
+    bx0 = max((xmin + 127) >> 8, cx0);
+    bx1 = min((xmax - 128) >> 8, cx1);
+    by0 = max((ymin + 127) >> 8, cy0);
+    by1 = min((ymax - 128) >> 8, cy1);
+    return bx0 <= bx1 && by0 <= by1;
+}
+
+// True when every edge-function value at a pixel of the triangle's own box fits 32 bits.
+__device__ inline bool narrow(const Tri &t)
+{
+    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
+    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
+    return (xmax - xmin) < 16384 && (ymax - ymin) < 16384;
+}
+
+// Top-left rule as a bias: an edge function of exactly 0 counts only on top or left edges, so
+// "inside" is E - bias >= 0 with bias 0 on those edges and 1 on the others.
+__device__ inline int32_t edge_bias(int32_t ex, int32_t ey) { return (ey < 0 || (ey == 0 && ex > 0)) ? 0 : 1; }
+
+// Does a narrow triangle cover at least one sample of its (small) pixel box?
+__device__ inline bool covers_any(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
+{
+    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
+    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
+    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+    const int32_t b0 = edge_bias(ex0, ey0), b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+    bool any = false;
+    for (int32_t j = by0; j <= by1; ++j)
+        for (int32_t i = bx0; i <= bx1; ++i) {
+            const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
+            const int32_t E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - b0;
+            const int32_t E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
+            const int32_t E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
+            any = any || ((E0 | E1 | E2) >= 0);
+        }
+    return any;
+}
+
+} // namespace sxe

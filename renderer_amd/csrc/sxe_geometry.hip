@@ -1,59 +1,27 @@
-// sxe_kernels.hip -- gfx950 kernels of the raster/shade path.
+// sxe_geometry.hip -- gfx950 kernels of the geometry half of the raster/shade path.
 //
 // Frame pipeline (all on one stream, no host round trip):
 //   k_object        PVM = (P*V)*M per object (standard.vert:28, matrix part) and a conservative
 //                   whole-object visibility test
-//   k_setup         one thread per submitted triangle: vertex transform, trivial reject, clip,
-//                   perspective divide, snap, orientation, bounding box, exact coverage test for
-//                   tiny boxes; writes one record per surviving triangle in submission order and
-//                   counts bin entries per screen tile
+//   k_setup         one thread per submitted triangle: vertex transform, trivial reject, perspective
+//                   divide, snap, orientation, bounding box, exact coverage test for tiny boxes;
+//                   writes one record per surviving triangle in submission order and counts bin
+//                   entries per screen tile
+//   k_clip          triangles that cross the near, far or a guard-band plane: Sutherland-Hodgman
+//                   and one record per triangle of the resulting fan
 //   k_scan          exclusive scan of the tile counts, totals, capacity check
 //   k_bin           scatters record slots into the per-tile bins (small boxes to the front of a
 //                   bin, the others to its back)
-//   k_raster_shade  one workgroup per 32x32 tile: coverage + depth in LDS with 64-bit
-//                   (depth | order) minima, then one deferred shade + store per pixel
+//   k_raster_shade  (sxe_raster.hip) one workgroup per 32x32 tile
 //
 // What the kernels replace in the reference is fixed-function Vulkan state selected at
-// src/renderer/drawer.rs:652-705 plus the two shaders under src/data/shaders/.
+// src/renderer/drawer.rs:652-705 plus the vertex shader src/data/shaders/standard.vert.
 //
 // Numeric contract: every float expression is evaluated as written (built with
 // -ffp-contract=off); coverage is exact integer arithmetic on 24.8 fixed-point vertices.
-#include "sxe_internal.h"
-#include "sxe_srgb_tables.h"
+#include "sxe_device.h"
 
 namespace sxe {
-
-__constant__ float c_srgb_decode[256];
-__constant__ float c_unorm8[256];
-__constant__ float c_srgb_thr[256];
-static bool g_tables_ready[64] = {};
-
-static hipError_t ensure_tables()
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 64 && g_tables_ready[dev]) return hipSuccess;
-    float thr[256];
-    for (int i = 0; i < 255; ++i) thr[i] = SXE_SRGB_ENCODE_THR[i];
-    thr[255] = __builtin_inff();
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_decode), SXE_SRGB_DECODE, sizeof(float) * 256)) != hipSuccess) return e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_unorm8), SXE_UNORM8, sizeof(float) * 256)) != hipSuccess) return e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_thr), thr, sizeof(float) * 256)) != hipSuccess) return e;
-    if (dev < 64) g_tables_ready[dev] = true;
-    return hipSuccess;
-}
-
-// gl_Position = PVM * (pos, 1) with each row summed left to right (standard.vert:28).
-__device__ inline float4 transform_vertex(const float *__restrict__ pvm, float x, float y, float z)
-{
-    float4 r;
-    r.x = ((pvm[0] * x + pvm[4] * y) + pvm[8] * z) + pvm[12];
-    r.y = ((pvm[1] * x + pvm[5] * y) + pvm[9] * z) + pvm[13];
-    r.z = ((pvm[2] * x + pvm[6] * y) + pvm[10] * z) + pvm[14];
-    r.w = ((pvm[3] * x + pvm[7] * y) + pvm[11] * z) + pvm[15];
-    return r;
-}
 
 // ------------------------------------------------------------------------------------------
 // Per-object kernels
@@ -172,85 +140,6 @@ __global__ __launch_bounds__(256) void k_vertex(const float *__restrict__ px, co
     float4 *dst = clip + (size_t)vb.clip_base + v0;
     for (int k = 0; k < 4; ++k)
         if (v0 + k < mesh.n_vtx) dst[k] = transform_vertex(pvm, xs[k], ys[k], zs[k]);
-}
-
-// ------------------------------------------------------------------------------------------
-// Triangle records
-// ------------------------------------------------------------------------------------------
-
-struct Tri { // one screen triangle as the raster and resolve loops use it
-    int32_t x0, y0, x1, y1, x2, y2;
-};
-
-__device__ inline bool fits16(int32_t d) { return d >= -32767 && d <= 32767; }
-
-__device__ inline Tri unpack_tri(const RastRec &r, const WideRec *__restrict__ wide, uint32_t slot)
-{
-    Tri t;
-    t.x0 = r.x0;
-    t.y0 = r.y0;
-    if (r.d1 == kWideTri) {
-        const WideRec w = wide[slot];
-        t.x1 = w.x1; t.y1 = w.y1; t.x2 = w.x2; t.y2 = w.y2;
-    } else {
-        t.x1 = r.x0 + (int32_t)(int16_t)(r.d1 & 0xFFFFu);
-        t.y1 = r.y0 + ((int32_t)r.d1 >> 16);
-        t.x2 = r.x0 + (int32_t)(int16_t)(r.d2 & 0xFFFFu);
-        t.y2 = r.y0 + ((int32_t)r.d2 >> 16);
-    }
-    return t;
-}
-
-// 1 / doubled area, as the setup stage defines it: the reciprocal of the area converted to float.
-__device__ inline float recip_area(const Tri &t)
-{
-    const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
-    return 1.0f / (float)area2;
-}
-
-// Inclusive pixel box of a triangle inside the rectangle [cx0,cx1] x [cy0,cy1].
-// Pixel (i,j) is sampled at (256 i + 128, 256 j + 128).
-__device__ inline bool pixel_box(const Tri &t, int32_t cx0, int32_t cx1, int32_t cy0, int32_t cy1, int32_t &bx0,
-                                 int32_t &bx1, int32_t &by0, int32_t &by1)
-{
-    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
-    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
-    bx0 = max((xmin + 127) >> 8, cx0);
-    bx1 = min((xmax - 128) >> 8, cx1);
-    by0 = max((ymin + 127) >> 8, cy0);
-    by1 = min((ymax - 128) >> 8, cy1);
-    return bx0 <= bx1 && by0 <= by1;
-}
-
-// True when every edge-function value at a pixel of the triangle's own box fits 32 bits.
-__device__ inline bool narrow(const Tri &t)
-{
-    const int32_t xmin = min(t.x0, min(t.x1, t.x2)), xmax = max(t.x0, max(t.x1, t.x2));
-    const int32_t ymin = min(t.y0, min(t.y1, t.y2)), ymax = max(t.y0, max(t.y1, t.y2));
-    return (xmax - xmin) < 16384 && (ymax - ymin) < 16384;
-}
-
-// Top-left rule as a bias: an edge function of exactly 0 counts only on top or left edges, so
-// "inside" is E - bias >= 0 with bias 0 on those edges and 1 on the others.
-__device__ inline int32_t edge_bias(int32_t ex, int32_t ey) { return (ey < 0 || (ey == 0 && ex > 0)) ? 0 : 1; }
-
-// Does a narrow triangle cover at least one sample of its (small) pixel box?
-__device__ inline bool covers_any(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
-{
-    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
-    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
-    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-    const int32_t b0 = edge_bias(ex0, ey0), b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
-    bool any = false;
-    for (int32_t j = by0; j <= by1; ++j)
-        for (int32_t i = bx0; i <= bx1; ++i) {
-            const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
-            const int32_t E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - b0;
-            const int32_t E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
-            const int32_t E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
-            any = any || ((E0 | E1 | E2) >= 0);
-        }
-    return any;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -745,296 +634,6 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Tile raster + deferred shade
-// ------------------------------------------------------------------------------------------
-
-__device__ inline uint32_t srgb_encode_lds(const float *thr, float x)
-{
-    // number of thresholds <= x; thr[255] = +inf
-    uint32_t lo = 0;
-    for (uint32_t step = 128; step; step >>= 1)
-        if (thr[lo + step - 1] <= x) lo += step;
-    return lo;
-}
-
-__device__ inline uint32_t unorm8_encode(float a)
-{
-    if (!(a > 0.0f)) a = 0.0f;
-    if (a > 1.0f) a = 1.0f;
-    return (uint32_t)(int)rintf(a * 255.0f);
-}
-
-// texture(sampler2D, uv) for a single-level RGBA8 sRGB image, linear filter, clamp to edge
-// (standard.frag:12; sampler at src/renderer/drawer.rs:231; format at src/renderer/types.rs:186).
-__device__ inline void sample_texture(const uint8_t *__restrict__ texels, const TexDev &t, const float *dec,
-                                      float u, float v, float out[4])
-{
-    const float fw = (float)t.width, fh = (float)t.height;
-    float x = u * fw - 0.5f, y = v * fh - 0.5f;
-    if (!(x >= -1.0f)) x = -1.0f;
-    if (x > fw) x = fw;
-    if (!(y >= -1.0f)) y = -1.0f;
-    if (y > fh) y = fh;
-    const float fx0 = floorf(x), fy0 = floorf(y);
-    const float ax = x - fx0, ay = y - fy0;
-    const int mw = (int)t.width - 1, mh = (int)t.height - 1;
-    const int ix0 = min(max((int)fx0, 0), mw), ix1 = min(max((int)fx0 + 1, 0), mw);
-    const int iy0 = min(max((int)fy0, 0), mh), iy1 = min(max((int)fy0 + 1, 0), mh);
-    const uint32_t *tx = reinterpret_cast<const uint32_t *>(texels) + t.offset;
-    const uint32_t t00 = tx[(size_t)iy0 * t.width + ix0], t10 = tx[(size_t)iy0 * t.width + ix1];
-    const uint32_t t01 = tx[(size_t)iy1 * t.width + ix0], t11 = tx[(size_t)iy1 * t.width + ix1];
-    for (int k = 0; k < 4; ++k) {
-        const int sh = 8 * k;
-        float c00, c10, c01, c11;
-        if (k < 3) {
-            c00 = dec[(t00 >> sh) & 255]; c10 = dec[(t10 >> sh) & 255];
-            c01 = dec[(t01 >> sh) & 255]; c11 = dec[(t11 >> sh) & 255];
-        } else {
-            c00 = c_unorm8[(t00 >> sh) & 255]; c10 = c_unorm8[(t10 >> sh) & 255];
-            c01 = c_unorm8[(t01 >> sh) & 255]; c11 = c_unorm8[(t11 >> sh) & 255];
-        }
-        const float top = c00 + ax * (c10 - c00);
-        const float bot = c01 + ax * (c11 - c01);
-        out[k] = top + ay * (bot - top);
-    }
-}
-
-__device__ inline float clamp_depth(float z)
-{
-    if (!(z > 0.0f)) z = 0.0f;
-    return z;
-}
-
-__device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint32_t order)
-{
-    if (z < 1.0f) { // a depth of 1.0 can never be Less than the cleared 1.0
-        const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | order;
-        unsigned long long *p = &vis[pix];
-        if (key < *p) atomicMin(p, key);
-    }
-}
-
-// One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions.
-__device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
-                                   int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
-{
-    // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
-    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
-    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
-    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
-    const float rA = 1.0f / (float)(ex2 * (t.y2 - t.y0) - (t.x2 - t.x0) * ey2);
-    const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
-    int32_t R0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - edge_bias(ex0, ey0);
-    int32_t R1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
-    int32_t R2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
-    const int32_t ax0 = -256 * ey0, ax1 = -256 * ey1, ax2 = -256 * ey2; // one pixel to the right
-    const int32_t ay0 = 256 * ex0, ay1 = 256 * ex1, ay2 = 256 * ex2;    // one pixel down
-    int32_t E0 = R0, E1 = R1, E2 = R2;
-    int32_t i = bx0, j = by0;
-    const int32_t cnt = (bx1 - bx0 + 1) * (by1 - by0 + 1);
-    for (int32_t k = 0; k < cnt; ++k) {
-        if ((E0 | E1 | E2) >= 0) {
-            const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
-            const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, r.order);
-        }
-        E0 += ax0; E1 += ax1; E2 += ax2;
-        if (++i > bx1) {
-            i = bx0;
-            ++j;
-            R0 += ay0; R1 += ay1; R2 += ay2;
-            E0 = R0; E1 = R1; E2 = R2;
-        }
-    }
-}
-
-template <bool COVERAGE>
-__global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
-{
-    __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | order, per pixel
-    __shared__ float s_thr[256];
-    __shared__ float s_dec[256];
-    if (a.counters->overflow) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
-    const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
-    const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
-    for (int i = tid; i < kTilePixels; i += kRasterThreads) vis[i] = kVisEmpty;
-    s_thr[tid] = c_srgb_thr[tid];
-    s_dec[tid] = c_srgb_decode[tid];
-    __syncthreads();
-
-    // rectangle of this tile that exists in the frame and the scissor (inclusive)
-    const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
-    const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
-
-    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : a.tile_count[tile], off = a.tile_off[tile];
-    const uint32_t n_front = min(a.fill_front[tile], n);
-    // two passes over the bin: the front part holds small boxes, the back part the others
-    for (int part = 0; part < 2; ++part) {
-        const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
-        for (uint32_t base = lo + (uint32_t)wave * 64u; base < hi; base += kRasterThreads) {
-            const uint32_t e = base + (uint32_t)lane;
-            const bool valid = e < hi;
-            bool wide_box = false;
-            RastRec r;
-            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
-            Tri t = {0, 0, 0, 0, 0, 0};
-            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-            if (valid) {
-                const uint32_t slot = a.bins[off + e];
-                r = a.rast[slot];
-                t = unpack_tri(r, a.wide, slot);
-                const bool nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
-                const bool alone = nonempty && (bx1 - bx0 + 1) * (by1 - by0 + 1) <= kLaneBox && narrow(t);
-                wide_box = nonempty && !alone;
-                if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, bx0, bx1, by0, by1, tpx, tpy);
-            }
-            // boxes too large for one lane: the whole wave walks the box, 64 pixels per step
-            unsigned long long lm = (a.debug & kDebugSkipLarge) ? 0ull : __ballot(wide_box);
-            while (lm) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
-                lm &= lm - 1;
-                Tri q;
-                q.x0 = __builtin_amdgcn_readlane(t.x0, src); q.y0 = __builtin_amdgcn_readlane(t.y0, src);
-                q.x1 = __builtin_amdgcn_readlane(t.x1, src); q.y1 = __builtin_amdgcn_readlane(t.y1, src);
-                q.x2 = __builtin_amdgcn_readlane(t.x2, src); q.y2 = __builtin_amdgcn_readlane(t.y2, src);
-                const float z0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.z0), src));
-                const float dz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.dz1), src));
-                const float dz2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r.dz2), src));
-                const uint32_t order = __builtin_amdgcn_readlane(r.order, src);
-                const int32_t qx0 = __builtin_amdgcn_readlane(bx0, src), qx1 = __builtin_amdgcn_readlane(bx1, src);
-                const int32_t qy0 = __builtin_amdgcn_readlane(by0, src), qy1 = __builtin_amdgcn_readlane(by1, src);
-                const float rA = recip_area(q);
-                const uint32_t bw = (uint32_t)(qx1 - qx0 + 1), cnt = bw * (uint32_t)(qy1 - qy0 + 1);
-                const uint32_t magic = (65536u + bw - 1u) / bw; // idx / bw == (idx * magic) >> 16 for idx < 1024, bw <= 32
-                if (narrow(q)) {
-                    // edge functions at the box origin (wave-uniform), then two multiply-adds per lane and edge
-                    const int32_t ex0 = q.x2 - q.x1, ey0 = q.y2 - q.y1;
-                    const int32_t ex1 = q.x0 - q.x2, ey1 = q.y0 - q.y2;
-                    const int32_t ex2 = q.x1 - q.x0, ey2 = q.y1 - q.y0;
-                    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
-                    const int32_t sx = 256 * qx0 + 128, sy = 256 * qy0 + 128;
-                    const int32_t R0 = ex0 * (sy - q.y1) - ey0 * (sx - q.x1) - edge_bias(ex0, ey0);
-                    const int32_t R1 = ex1 * (sy - q.y2) - ey1 * (sx - q.x2) - b1;
-                    const int32_t R2 = ex2 * (sy - q.y0) - ey2 * (sx - q.x0) - b2;
-                    for (uint32_t idx = (uint32_t)lane; idx < cnt; idx += 64u) {
-                        const uint32_t row = (idx * magic) >> 16;
-                        const int32_t di = (int32_t)(idx - row * bw), dj = (int32_t)row;
-                        const int32_t E0 = R0 - 256 * ey0 * di + 256 * ex0 * dj;
-                        const int32_t E1 = R1 - 256 * ey1 * di + 256 * ex1 * dj;
-                        const int32_t E2 = R2 - 256 * ey2 * di + 256 * ex2 * dj;
-                        if ((E0 | E1 | E2) >= 0) {
-                            const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
-                            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
-                            depth_min(vis, (qy0 + dj - tpy) * kTile + (qx0 + di - tpx), z, order);
-                        }
-                    }
-                } else {
-                    const long long ex0 = q.x2 - q.x1, ey0 = q.y2 - q.y1;
-                    const long long ex1 = q.x0 - q.x2, ey1 = q.y0 - q.y2;
-                    const long long ex2 = q.x1 - q.x0, ey2 = q.y1 - q.y0;
-                    const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
-                                    b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
-                    for (uint32_t idx = (uint32_t)lane; idx < cnt; idx += 64u) {
-                        const uint32_t row = (idx * magic) >> 16;
-                        const int32_t i = qx0 + (int32_t)(idx - row * bw), j = qy0 + (int32_t)row;
-                        const long long sx = 256 * i + 128, sy = 256 * j + 128;
-                        const long long E0 = ex0 * (sy - q.y1) - ey0 * (sx - q.x1);
-                        const long long E1 = ex1 * (sy - q.y2) - ey1 * (sx - q.x2);
-                        const long long E2 = ex2 * (sy - q.y0) - ey2 * (sx - q.x0);
-                        if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
-                            const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
-                            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
-                            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, order);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (a.debug & kDebugSkipResolve) return;
-
-    // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target ----
-    const float clr_r = s_dec[a.clear_code & 255], clr_g = s_dec[(a.clear_code >> 8) & 255];
-    const float clr_b = s_dec[(a.clear_code >> 16) & 255], clr_a = c_unorm8[(a.clear_code >> 24) & 255];
-    for (int k = 0; k < kTilePixels / kRasterThreads; ++k) {
-        const int lx = tid & (kTile - 1), ly = (tid / kTile) + k * (kRasterThreads / kTile);
-        const int32_t i = tpx + lx, j = tpy + ly;
-        if (i > cx1 || j < cy0 || j > cy1) continue;
-        const unsigned long long key = vis[ly * kTile + lx];
-        const size_t p = (size_t)j * a.g.width + (size_t)i;
-        uint32_t code = a.clear_code, prim = 0xFFFFFFFFu;
-        float depth = 1.0f;
-        if (key != kVisEmpty) {
-            uint32_t slot = (uint32_t)key;
-            depth = __uint_as_float((uint32_t)(key >> 32));
-            ShadeRec h = a.shade[slot];
-            const long long sx = 256 * i + 128, sy = 256 * j + 128;
-            const uint32_t n_fan = h.tex_fan >> 24;
-            if (n_fan) {
-                // a clipped triangle won: exactly one triangle of its fan covers this sample
-                const uint32_t fan_base = h.fan_base;
-                for (uint32_t f = 0; f < n_fan; ++f) {
-                    const RastRec fr = a.rast[fan_base + f];
-                    if (fr.x0 == kNoRaster) continue;
-                    const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
-                    const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
-                                    fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
-                    const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
-                    const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
-                    const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
-                    if ((E0 | E1 | E2) >= 0) {
-                        slot = fan_base + f;
-                        break;
-                    }
-                }
-                h = a.shade[slot];
-            }
-            const Tri t = unpack_tri(a.rast[slot], a.wide, slot);
-            prim = h.prim;
-            const float rA = recip_area(t);
-            const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
-            const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
-            const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
-            const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
-            const float riw = 1.0f / iw;
-            float src[4];
-            if (a.shading == SXE_SHADE_VERTEX_COLOR) {
-                const ColorRec c = a.color[slot];
-                src[0] = ((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw;
-                src[1] = ((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw;
-                src[2] = ((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw;
-                src[3] = 1.0f;
-            } else {
-                const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
-                const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
-                sample_texture(a.texels, a.textures[h.tex_fan & 0xFFFFFFu], s_dec, u, v, src);
-                if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
-                    const ColorRec c = a.color[slot];
-                    src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
-                    src[1] = (((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw) * src[1];
-                    src[2] = (((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw) * src[2];
-                }
-            }
-            // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target
-            const float sa = src[3], ia = 1.0f - sa;
-            const uint32_t cr = srgb_encode_lds(s_thr, src[0] * sa + clr_r * ia);
-            const uint32_t cg = srgb_encode_lds(s_thr, src[1] * sa + clr_g * ia);
-            const uint32_t cb = srgb_encode_lds(s_thr, src[2] * sa + clr_b * ia);
-            const uint32_t ca = unorm8_encode(sa + clr_a * ia);
-            code = cr | (cg << 8) | (cb << 16) | (ca << 24);
-        }
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = code;
-        a.out_depth[p] = depth;
-        if (COVERAGE) a.out_prim[p] = prim;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
 
@@ -1093,18 +692,6 @@ hipError_t launch_bin(const BinArgs &a, hipStream_t s)
 {
     if (a.n_blocks + a.fan_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bin, dim3(a.n_blocks + a.fan_blocks), dim3(kSetupThreads), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
-{
-    hipError_t e = ensure_tables();
-    if (e != hipSuccess) return e;
-    if (a.g.n_tiles == 0) return hipSuccess;
-    if (a.out_prim)
-        hipLaunchKernelGGL(k_raster_shade<true>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_raster_shade<false>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
     return hipGetLastError();
 }
 

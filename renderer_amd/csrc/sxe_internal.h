@@ -185,6 +185,7 @@ struct RasterArgs {
     const FrameCounters *counters;
     const uint8_t *texels;
     const TexDev *textures;
+    uint32_t n_textures;
     uint8_t *out_color;   // RGBA8, row-major, full frame
     float *out_depth;
     uint32_t *out_prim;   // may be null

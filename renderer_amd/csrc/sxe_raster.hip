@@ -1,0 +1,512 @@
+// sxe_raster.hip -- the tile kernel of the raster/shade path (gfx950).
+//
+// k_raster_shade: one workgroup per 32x32 screen tile.
+//   1. coverage + depth: every bin entry is tested against the tile's pixels with exact fixed-point
+//      edge functions and the top-left rule; depth test Less + write (src/renderer/drawer.rs:698-705)
+//      is a 64-bit minimum of (depth bits | submission order) per pixel in LDS, so the result does
+//      not depend on the order in which entries are processed;
+//   2. resolve: the winning triangle of every pixel is shaded once (standard.frag:12: bilinear sRGB
+//      texture fetch with perspective-correct uv), blended over the cleared target
+//      (BlendState::ALPHA, drawer.rs:660-663), encoded to sRGB8 and stored together with the
+//      depth; the clear (drawer.rs:307-308) is fused, so the frame is written exactly once.
+//
+// Numeric contract: every float expression is evaluated as written (-ffp-contract=off).
+#include "sxe_device.h"
+#include "sxe_srgb_tables.h"
+
+namespace sxe {
+
+__constant__ float c_srgb_decode[256];
+__constant__ float c_unorm8[256];
+__constant__ float c_srgb_thr[256];
+static bool g_tables_ready[64] = {};
+
+static hipError_t ensure_tables()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && g_tables_ready[dev]) return hipSuccess;
+    float thr[256];
+    for (int i = 0; i < 255; ++i) thr[i] = SXE_SRGB_ENCODE_THR[i];
+    thr[255] = __builtin_inff();
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_decode), SXE_SRGB_DECODE, sizeof(float) * 256)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_unorm8), SXE_UNORM8, sizeof(float) * 256)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_thr), thr, sizeof(float) * 256)) != hipSuccess) return e;
+    if (dev < 64) g_tables_ready[dev] = true;
+    return hipSuccess;
+}
+
+constexpr int kWideQueue = 512;   // wide-box entries of one tile that all four waves share
+constexpr int kTexCache = 64;     // texture descriptors kept in LDS
+constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
+
+// Linear value -> sRGB8 code = number of thresholds <= x (thr[255] = +inf).  The hardware
+// log2/exp2 give a candidate within one code of the answer; two table compares make it exact, so
+// the approximation never shows in the output.
+__device__ inline uint32_t srgb_encode_lds(const float *thr, float x)
+{
+    const float y = (x <= 0.0031308f) ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.41666666f) - 0.055f;
+    int c = (int)(y * 255.0f + 0.5f);
+    c = min(max(c, 0), 255);
+    if (c > 0 && !(thr[c - 1] <= x)) --c;
+    else if (thr[c] <= x) ++c;
+    return (uint32_t)c;
+}
+
+__device__ inline uint32_t unorm8_encode(float a)
+{
+    if (!(a > 0.0f)) a = 0.0f;
+    if (a > 1.0f) a = 1.0f;
+    return (uint32_t)(int)rintf(a * 255.0f);
+}
+
+// texture(sampler2D, uv) for a single-level RGBA8 sRGB image, linear filter, clamp to edge
+// (standard.frag:12; sampler at src/renderer/drawer.rs:231; format at src/renderer/types.rs:186),
+// split into texel addressing and filtering so that the four fetches of several pixels overlap.
+struct TexelQuad {
+    uint32_t i00, i10, i01, i11; // texel indices into the pooled texel buffer
+    float ax, ay;
+};
+
+__device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
+{
+    const float fw = (float)t.width, fh = (float)t.height;
+    float x = u * fw - 0.5f, y = v * fh - 0.5f;
+    if (!(x >= -1.0f)) x = -1.0f;
+    if (x > fw) x = fw;
+    if (!(y >= -1.0f)) y = -1.0f;
+    if (y > fh) y = fh;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    TexelQuad q;
+    q.ax = x - fx0;
+    q.ay = y - fy0;
+    const int mw = (int)t.width - 1, mh = (int)t.height - 1;
+    const int ix0 = min(max((int)fx0, 0), mw), ix1 = min(max((int)fx0 + 1, 0), mw);
+    const int iy0 = min(max((int)fy0, 0), mh), iy1 = min(max((int)fy0 + 1, 0), mh);
+    q.i00 = t.offset + (uint32_t)iy0 * t.width + (uint32_t)ix0;
+    q.i10 = t.offset + (uint32_t)iy0 * t.width + (uint32_t)ix1;
+    q.i01 = t.offset + (uint32_t)iy1 * t.width + (uint32_t)ix0;
+    q.i11 = t.offset + (uint32_t)iy1 * t.width + (uint32_t)ix1;
+    return q;
+}
+
+// sRGB decode of every texel before filtering; alpha is linear.
+__device__ inline void filter_quad(const float *dec, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, float ax,
+                                   float ay, float out[4])
+{
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 8 * k;
+        float c00, c10, c01, c11;
+        if (k < 3) {
+            c00 = dec[(t00 >> sh) & 255]; c10 = dec[(t10 >> sh) & 255];
+            c01 = dec[(t01 >> sh) & 255]; c11 = dec[(t11 >> sh) & 255];
+        } else {
+            c00 = c_unorm8[(t00 >> sh) & 255]; c10 = c_unorm8[(t10 >> sh) & 255];
+            c01 = c_unorm8[(t01 >> sh) & 255]; c11 = c_unorm8[(t11 >> sh) & 255];
+        }
+        const float top = c00 + ax * (c10 - c00);
+        const float bot = c01 + ax * (c11 - c01);
+        out[k] = top + ay * (bot - top);
+    }
+}
+
+__device__ inline float clamp_depth(float z)
+{
+    if (!(z > 0.0f)) z = 0.0f;
+    return z;
+}
+
+__device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint32_t order)
+{
+    if (z < 1.0f) { // a depth of 1.0 can never be Less than the cleared 1.0
+        const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | order;
+        unsigned long long *p = &vis[pix];
+        if (key < *p) atomicMin(p, key);
+    }
+}
+
+// One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions.
+__device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
+                                   int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
+{
+    // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
+    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
+    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
+    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+    const float rA = 1.0f / (float)(ex2 * (t.y2 - t.y0) - (t.x2 - t.x0) * ey2);
+    const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
+    int32_t R0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - edge_bias(ex0, ey0);
+    int32_t R1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
+    int32_t R2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
+    const int32_t ax0 = -256 * ey0, ax1 = -256 * ey1, ax2 = -256 * ey2; // one pixel to the right
+    const int32_t ay0 = 256 * ex0, ay1 = 256 * ex1, ay2 = 256 * ex2;    // one pixel down
+    int32_t E0 = R0, E1 = R1, E2 = R2;
+    int32_t i = bx0, j = by0;
+    const int32_t cnt = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    for (int32_t k = 0; k < cnt; ++k) {
+        if ((E0 | E1 | E2) >= 0) {
+            const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
+            const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
+            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, r.order);
+        }
+        E0 += ax0; E1 += ax1; E2 += ax2;
+        if (++i > bx1) {
+            i = bx0;
+            ++j;
+            R0 += ay0; R1 += ay1; R2 += ay2;
+            E0 = R0; E1 = R1; E2 = R2;
+        }
+    }
+}
+
+// Wide boxes: each lane prepares one triangle (edge functions at the box origin, reciprocal area,
+// row divider), then the wave takes the triangles one at a time, 64 pixels per step; `first` and
+// `stride` let several waves interleave their steps on the same triangle.
+struct WideSetup {
+    int32_t ex0, ey0, ex1, ey1, ex2, ey2; // edge vectors
+    int32_t R0, R1, R2;                   // biased edge functions at the first pixel of the box
+    int32_t b1, b2;
+    float rA;
+    int32_t qx0, qy0;
+    uint32_t bw, cnt, magic;              // idx / bw == (idx * magic) >> 16 for idx < 1024, bw <= 32
+    bool is_narrow;
+};
+
+__device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
+{
+    WideSetup w;
+    w.ex0 = t.x2 - t.x1; w.ey0 = t.y2 - t.y1;
+    w.ex1 = t.x0 - t.x2; w.ey1 = t.y0 - t.y2;
+    w.ex2 = t.x1 - t.x0; w.ey2 = t.y1 - t.y0;
+    w.b1 = edge_bias(w.ex1, w.ey1);
+    w.b2 = edge_bias(w.ex2, w.ey2);
+    w.is_narrow = narrow(t);
+    const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
+    // meaningful for narrow triangles only (every product below 2^28); others use the 64-bit loop
+    w.R0 = w.ex0 * (sy - t.y1) - w.ey0 * (sx - t.x1) - edge_bias(w.ex0, w.ey0);
+    w.R1 = w.ex1 * (sy - t.y2) - w.ey1 * (sx - t.x2) - w.b1;
+    w.R2 = w.ex2 * (sy - t.y0) - w.ey2 * (sx - t.x0) - w.b2;
+    w.rA = recip_area(t);
+    w.qx0 = bx0; w.qy0 = by0;
+    w.bw = (uint32_t)(bx1 - bx0 + 1);
+    w.cnt = w.bw * (uint32_t)(by1 - by0 + 1);
+    w.magic = (65536u + w.bw - 1u) / w.bw;
+    return w;
+}
+
+#define SXE_RL(x) __builtin_amdgcn_readlane((int)(x), src)
+#define SXE_RLF(x) __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), src))
+
+// Rasterise the triangle prepared by lane `src` with the whole wave.
+__device__ inline void raster_wide(unsigned long long *vis, int src, const WideSetup &w, const Tri &t, const RastRec &r,
+                                   uint32_t first, uint32_t stride, int32_t tpx, int32_t tpy)
+{
+    const float z0 = SXE_RLF(r.z0), dz1 = SXE_RLF(r.dz1), dz2 = SXE_RLF(r.dz2), rA = SXE_RLF(w.rA);
+    const uint32_t order = (uint32_t)SXE_RL(r.order);
+    const int32_t qx0 = SXE_RL(w.qx0), qy0 = SXE_RL(w.qy0);
+    const uint32_t bw = (uint32_t)SXE_RL(w.bw), cnt = (uint32_t)SXE_RL(w.cnt), magic = (uint32_t)SXE_RL(w.magic);
+    if (SXE_RL(w.is_narrow ? 1 : 0)) {
+        const int32_t R0 = SXE_RL(w.R0), R1 = SXE_RL(w.R1), R2 = SXE_RL(w.R2), b1 = SXE_RL(w.b1), b2 = SXE_RL(w.b2);
+        // one pixel to the right / one pixel down
+        const int32_t ax0 = -256 * SXE_RL(w.ey0), ax1 = -256 * SXE_RL(w.ey1), ax2 = -256 * SXE_RL(w.ey2);
+        const int32_t ay0 = 256 * SXE_RL(w.ex0), ay1 = 256 * SXE_RL(w.ex1), ay2 = 256 * SXE_RL(w.ex2);
+        for (uint32_t idx = first; idx < cnt; idx += stride) {
+            const uint32_t row = (idx * magic) >> 16;
+            const int32_t di = (int32_t)(idx - row * bw), dj = (int32_t)row;
+            const int32_t E0 = R0 + ax0 * di + ay0 * dj;
+            const int32_t E1 = R1 + ax1 * di + ay1 * dj;
+            const int32_t E2 = R2 + ax2 * di + ay2 * dj;
+            if ((E0 | E1 | E2) >= 0) {
+                const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
+                const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+                depth_min(vis, (qy0 + dj - tpy) * kTile + (qx0 + di - tpx), z, order);
+            }
+        }
+    } else {
+        const long long x0 = SXE_RL(t.x0), y0 = SXE_RL(t.y0), x1 = SXE_RL(t.x1), y1 = SXE_RL(t.y1), x2 = SXE_RL(t.x2), y2 = SXE_RL(t.y2);
+        const long long ex0 = x2 - x1, ey0 = y2 - y1, ex1 = x0 - x2, ey1 = y0 - y2, ex2 = x1 - x0, ey2 = y1 - y0;
+        const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
+                        b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
+        for (uint32_t idx = first; idx < cnt; idx += stride) {
+            const uint32_t row = (idx * magic) >> 16;
+            const int32_t i = qx0 + (int32_t)(idx - row * bw), j = qy0 + (int32_t)row;
+            const long long sx = 256 * i + 128, sy = 256 * j + 128;
+            const long long E0 = ex0 * (sy - y1) - ey0 * (sx - x1);
+            const long long E1 = ex1 * (sy - y2) - ey1 * (sx - x2);
+            const long long E2 = ex2 * (sy - y0) - ey2 * (sx - x0);
+            if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
+                const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
+                const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+                depth_min(vis, (j - tpy) * kTile + (i - tpx), z, order);
+            }
+        }
+    }
+}
+
+template <bool COVERAGE>
+__global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
+{
+    __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | order, per pixel
+    __shared__ float s_thr[256];
+    __shared__ float s_dec[256];
+    __shared__ TexDev s_tex[kTexCache];
+    __shared__ uint32_t s_wq[kWideQueue];
+    __shared__ uint32_t s_nwq, s_ncov;
+    __shared__ uint16_t s_cov[kTilePixels]; // tile-local indices of the covered pixels
+    if (a.counters->overflow) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
+    const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
+    for (int i = tid; i < kTilePixels; i += kRasterThreads) vis[i] = kVisEmpty;
+    s_thr[tid] = c_srgb_thr[tid];
+    s_dec[tid] = c_srgb_decode[tid];
+    if (tid < kTexCache && (uint32_t)tid < a.n_textures) s_tex[tid] = a.textures[tid];
+    if (tid == 0) { s_nwq = 0; s_ncov = 0; }
+    __syncthreads();
+
+    // rectangle of this tile that exists in the frame and the scissor (inclusive)
+    const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
+    const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
+
+    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : a.tile_count[tile], off = a.tile_off[tile];
+    const uint32_t n_front = min(a.fill_front[tile], n);
+    // two passes over the bin: the front part holds small boxes, the back part the others
+    for (int part = 0; part < 2; ++part) {
+        const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
+        for (uint32_t base = lo + (uint32_t)wave * 64u; base < hi; base += kRasterThreads) {
+            const uint32_t e = base + (uint32_t)lane;
+            const bool valid = e < hi;
+            bool wide_box = false;
+            RastRec r;
+            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
+            Tri t = {0, 0, 0, 0, 0, 0};
+            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            if (valid) {
+                const uint32_t slot = a.bins[off + e];
+                r = a.rast[slot];
+                t = unpack_tri(r, a.wide, slot);
+                const bool nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
+                const bool alone = nonempty && (bx1 - bx0 + 1) * (by1 - by0 + 1) <= kLaneBox && narrow(t);
+                wide_box = nonempty && !alone && !(a.debug & kDebugSkipLarge);
+                if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, bx0, bx1, by0, by1, tpx, tpy);
+                if (a.debug & kDebugSkipAtomic) { // development census of the two raster paths
+                    FrameCounters *ctr = const_cast<FrameCounters *>(a.counters);
+                    const uint32_t box = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+                    if (wide_box) { atomicAdd(&ctr->pad[0], 1u); atomicAdd(&ctr->pad[1], box); }
+                    if (alone) atomicAdd(&ctr->pad[2], box);
+                }
+                if (wide_box) {
+                    // boxes too large for one lane are shared by all four waves after this pass
+                    const uint32_t qi = atomicAdd(&s_nwq, 1u);
+                    if (qi < kWideQueue) {
+                        s_wq[qi] = slot;
+                        wide_box = false;
+                    }
+                }
+            }
+            // queue full: this wave walks the box on its own, 64 pixels per step
+            unsigned long long lm = __ballot(wide_box);
+            if (lm) {
+                const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
+                while (lm) {
+                    const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                    lm &= lm - 1;
+                    raster_wide(vis, src, ws, t, r, (uint32_t)lane, 64u, tpx, tpy);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // every wave loads the queued triangles and takes every fourth 64-pixel step of each
+        const uint32_t nq = min(s_nwq, (uint32_t)kWideQueue);
+        for (uint32_t base = 0; base < nq; base += 64u) {
+            const uint32_t e = base + (uint32_t)lane;
+            const bool valid = e < nq;
+            RastRec r;
+            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
+            Tri t = {0, 0, 0, 0, 0, 0};
+            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            if (valid) {
+                const uint32_t slot = s_wq[e];
+                r = a.rast[slot];
+                t = unpack_tri(r, a.wide, slot);
+                pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
+            }
+            const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
+            unsigned long long lm = __ballot(valid);
+            while (lm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
+                lm &= lm - 1;
+                raster_wide(vis, src, ws, t, r, (uint32_t)(wave * 64 + lane), (uint32_t)kRasterThreads, tpx, tpy);
+            }
+        }
+    }
+    __syncthreads();
+    if (a.debug & kDebugSkipResolve) return;
+
+    // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target.
+    // A thread owns kTilePixels / kRasterThreads pixels and handles them kResolveBatch at a time,
+    // stage by stage, so that the dependent loads of one stage are in flight together. ----
+    const float clr_r = s_dec[a.clear_code & 255], clr_g = s_dec[(a.clear_code >> 8) & 255];
+    const float clr_b = s_dec[(a.clear_code >> 16) & 255], clr_a = c_unorm8[(a.clear_code >> 24) & 255];
+    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
+    // Uncovered pixels only need the clear values; covered ones are gathered into a dense list
+    // first so that the shading loop runs with full waves.
+    for (int k = 0; k < kTilePixels / kRasterThreads; ++k) {
+        const int lx = tid & (kTile - 1), ly = (tid / kTile) + k * (kRasterThreads / kTile);
+        const int32_t i = tpx + lx, j = tpy + ly;
+        const bool in_rect = !(i > cx1 || j < cy0 || j > cy1);
+        const bool covered = in_rect && vis[ly * kTile + lx] != kVisEmpty;
+        if (in_rect && !covered) {
+            const size_t p = (size_t)j * a.g.width + (size_t)i;
+            reinterpret_cast<uint32_t *>(a.out_color)[p] = a.clear_code;
+            a.out_depth[p] = 1.0f;
+            if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
+        }
+        const unsigned long long m = __ballot(covered);
+        if (m) {
+            uint32_t at = 0;
+            if (lane == __ffsll((long long)m) - 1) at = atomicAdd(&s_ncov, (uint32_t)__popcll(m));
+            at = __builtin_amdgcn_readlane(at, __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+            if (covered) s_cov[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(ly * kTile + lx);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cov = s_ncov;
+    for (uint32_t q0 = (uint32_t)tid; q0 < n_cov; q0 += kRasterThreads * kResolveBatch) {
+        bool live[kResolveBatch], cov[kResolveBatch];
+        uint32_t slot[kResolveBatch], prim[kResolveBatch], code[kResolveBatch];
+        float depth[kResolveBatch];
+        int32_t px[kResolveBatch], py[kResolveBatch];
+        ShadeRec h[kResolveBatch];
+        RastRec r[kResolveBatch];
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b) {
+            const uint32_t q = q0 + (uint32_t)b * kRasterThreads;
+            live[b] = cov[b] = q < n_cov;
+            const uint32_t pix = cov[b] ? s_cov[q] : 0u;
+            px[b] = tpx + (int32_t)(pix & (kTile - 1));
+            py[b] = tpy + (int32_t)(pix / kTile);
+            const unsigned long long key = vis[pix];
+            slot[b] = (uint32_t)key;
+            depth[b] = __uint_as_float((uint32_t)(key >> 32));
+            prim[b] = 0xFFFFFFFFu;
+            code[b] = a.clear_code;
+        }
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b)
+            if (cov[b]) {
+                h[b] = a.shade[slot[b]];
+                r[b] = a.rast[slot[b]];
+            }
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b)
+            if (cov[b] && (h[b].tex_fan >> 24)) {
+                // a clipped triangle won: exactly one triangle of its fan covers this sample
+                const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
+                const uint32_t fan_base = h[b].fan_base, n_fan = h[b].tex_fan >> 24;
+                for (uint32_t f = 0; f < n_fan; ++f) {
+                    const RastRec fr = a.rast[fan_base + f];
+                    if (fr.x0 == kNoRaster) continue;
+                    const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
+                    const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
+                                    fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
+                    const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
+                    const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
+                    const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
+                    if ((E0 | E1 | E2) >= 0) {
+                        slot[b] = fan_base + f;
+                        r[b] = fr;
+                        break;
+                    }
+                }
+                h[b] = a.shade[slot[b]];
+            }
+        float l1[kResolveBatch], l2[kResolveBatch], riw[kResolveBatch];
+        TexelQuad tq[kResolveBatch];
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b)
+            if (cov[b]) {
+                const Tri t = unpack_tri(r[b], a.wide, slot[b]);
+                prim[b] = h[b].prim;
+                const float rA = recip_area(t);
+                const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
+                const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
+                const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
+                l1[b] = (float)E1 * rA;
+                l2[b] = (float)E2 * rA;
+                const float iw = (h[b].iw0 + l1[b] * h[b].diw1) + l2[b] * h[b].diw2;
+                riw[b] = 1.0f / iw;
+                if (a.shading != SXE_SHADE_VERTEX_COLOR) {
+                    const float u = ((h[b].uw0 + l1[b] * h[b].duw1) + l2[b] * h[b].duw2) * riw[b];
+                    const float v = ((h[b].vw0 + l1[b] * h[b].dvw1) + l2[b] * h[b].dvw2) * riw[b];
+                    const uint32_t ti = h[b].tex_fan & 0xFFFFFFu;
+                    const TexDev td = ti < (uint32_t)kTexCache ? s_tex[ti] : a.textures[ti];
+                    tq[b] = texel_quad(td, u, v);
+                }
+            }
+        uint32_t t00[kResolveBatch], t10[kResolveBatch], t01[kResolveBatch], t11[kResolveBatch];
+        if (a.shading != SXE_SHADE_VERTEX_COLOR) {
+#pragma unroll
+            for (int b = 0; b < kResolveBatch; ++b)
+                if (cov[b]) {
+                    t00[b] = texels[tq[b].i00]; t10[b] = texels[tq[b].i10];
+                    t01[b] = texels[tq[b].i01]; t11[b] = texels[tq[b].i11];
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b)
+            if (cov[b]) {
+                float src[4];
+                if (a.shading == SXE_SHADE_VERTEX_COLOR) {
+                    const ColorRec c = a.color[slot[b]];
+                    src[0] = ((c.rw0 + l1[b] * c.drw1) + l2[b] * c.drw2) * riw[b];
+                    src[1] = ((c.gw0 + l1[b] * c.dgw1) + l2[b] * c.dgw2) * riw[b];
+                    src[2] = ((c.bw0 + l1[b] * c.dbw1) + l2[b] * c.dbw2) * riw[b];
+                    src[3] = 1.0f;
+                } else {
+                    filter_quad(s_dec, t00[b], t10[b], t01[b], t11[b], tq[b].ax, tq[b].ay, src);
+                    if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
+                        const ColorRec c = a.color[slot[b]];
+                        src[0] = (((c.rw0 + l1[b] * c.drw1) + l2[b] * c.drw2) * riw[b]) * src[0];
+                        src[1] = (((c.gw0 + l1[b] * c.dgw1) + l2[b] * c.dgw2) * riw[b]) * src[1];
+                        src[2] = (((c.bw0 + l1[b] * c.dbw1) + l2[b] * c.dbw2) * riw[b]) * src[2];
+                    }
+                }
+                // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target
+                const float sa = src[3], ia = 1.0f - sa;
+                const uint32_t cr = srgb_encode_lds(s_thr, src[0] * sa + clr_r * ia);
+                const uint32_t cg = srgb_encode_lds(s_thr, src[1] * sa + clr_g * ia);
+                const uint32_t cb = srgb_encode_lds(s_thr, src[2] * sa + clr_b * ia);
+                const uint32_t ca = unorm8_encode(sa + clr_a * ia);
+                code[b] = cr | (cg << 8) | (cb << 16) | (ca << 24);
+            }
+#pragma unroll
+        for (int b = 0; b < kResolveBatch; ++b)
+            if (live[b]) {
+                const size_t p = (size_t)py[b] * a.g.width + (size_t)px[b];
+                reinterpret_cast<uint32_t *>(a.out_color)[p] = code[b];
+                a.out_depth[p] = depth[b];
+                if (COVERAGE) a.out_prim[p] = prim[b];
+            }
+    }
+}
+
+hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
+{
+    hipError_t e = ensure_tables();
+    if (e != hipSuccess) return e;
+    if (a.g.n_tiles == 0) return hipSuccess;
+    if (a.out_prim)
+        hipLaunchKernelGGL(k_raster_shade<true>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_raster_shade<false>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace sxe
