@@ -176,6 +176,10 @@ int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
 /* Diagnostics: bin occupancy of the last frame, one count per rendered tile in row-major tile
  * order (load-balance analysis; no counterpart in the reference). */
 int sxe_read_tile_counts(sxe_ctx *ctx, uint32_t *counts, size_t size_bytes);
+/* Diagnostics: device clock (100 MHz) stamps of every tile's workgroup in the last frame, eight
+ * values per tile (0: start, 1: after initialisation, 2-4: coverage phases, 5: compaction,
+ * 7: end; 6 unused); only for contexts created with the development flag 1u << 26. */
+int sxe_read_tile_times(sxe_ctx *ctx, uint64_t *clocks, size_t size_bytes);
 int sxe_get_stats(sxe_ctx *ctx, sxe_frame_stats *out);
 
 /* ---- host-side Transform / camera maths (no device needed) ---- */

@@ -93,6 +93,7 @@ struct sxe_ctx {
     DevBuf<ColorRec> color;
     DevBuf<FrameCounters> counters;
     DevBuf<float4> clip;
+    DevBuf<unsigned long long> tile_times;
     FrameCounters *h_counters = nullptr; // pinned
     size_t fan_capacity = 0, bin_capacity = 0; // records past the per-workgroup segments; bin entries
 
@@ -423,6 +424,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ra.clear_code = srgb_encode_host(c->cfg.clear[0]) | (srgb_encode_host(c->cfg.clear[1]) << 8) |
                     (srgb_encode_host(c->cfg.clear[2]) << 16) | (unorm8_host(c->cfg.clear[3]) << 24);
     ra.shading = c->cfg.shading;
+    ra.tile_times = (c->cfg.flags & kDebugTileTimes) ? c->tile_times.p : nullptr;
     ra.debug = c->cfg.flags & kDebugMask;
     SXE_HIP(c, launch_raster_shade(ra, s));
     if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_RASTER], s));
@@ -551,6 +553,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((e = c->tile_counters.reserve(3 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_off.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile offsets)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
+    if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
     if ((e = c->textab.reserve(1)) != hipSuccess) return bail("hipMalloc(texture table)", e);
     *out = c;
@@ -567,7 +570,7 @@ void sxe_destroy(sxe_ctx *c)
     c->models.release(); c->pvm.release(); c->transforms.release(); c->texels.release(); c->textab.release();
     c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->visible.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
-    c->clip.release();
+    c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (int i = 0; i < EV_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -852,6 +855,19 @@ int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
     rc = sxe_sync(c);
     if (rc) return rc;
     if (need) SXE_HIP(c, hipMemcpy(counts, c->tile_counters.p, need, hipMemcpyDeviceToHost));
+    return SXE_OK;
+}
+
+int sxe_read_tile_times(sxe_ctx *c, uint64_t *clocks, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->tile_times.p) return fail(c, SXE_E_STATE, "tile clocks were not requested when the context was created");
+    const size_t need = (size_t)c->g.n_tiles * 64;
+    if (!clocks || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    rc = sxe_sync(c);
+    if (rc) return rc;
+    if (need) SXE_HIP(c, hipMemcpy(clocks, c->tile_times.p, need, hipMemcpyDeviceToHost));
     return SXE_OK;
 }
 

@@ -23,7 +23,8 @@ constexpr int32_t kNoRaster = INT32_MIN; // RastRec.x0 of a slot that holds no t
 // development-only switches carried in sxe_config.flags (timing experiments; outputs are wrong)
 constexpr uint32_t kDebugSkipRaster = 1u << 30, kDebugSkipResolve = 1u << 31;
 constexpr uint32_t kDebugSkipSmall = 1u << 28, kDebugSkipLarge = 1u << 29, kDebugSkipAtomic = 1u << 27;
-constexpr uint32_t kDebugMask = 31u << 27;
+constexpr uint32_t kDebugTileTimes = 1u << 26; // record start/end clock of every tile workgroup
+constexpr uint32_t kDebugMask = 63u << 26;
 
 // overflow bits of FrameCounters::overflow
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
@@ -189,6 +190,7 @@ struct RasterArgs {
     uint8_t *out_color;   // RGBA8, row-major, full frame
     float *out_depth;
     uint32_t *out_prim;   // may be null
+    unsigned long long *tile_times; // development: 8 clock values per tile (phase stamps), or null
     uint32_t clear_code;  // encoded clear colour, little-endian RGBA
     uint32_t shading;
     uint32_t debug;

@@ -40,6 +40,7 @@ static hipError_t ensure_tables()
 constexpr int kWideQueue = 512;   // wide-box entries of one tile that all four waves share
 constexpr int kTexCache = 64;     // texture descriptors kept in LDS
 constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
+constexpr int kEntriesPerLane = 2; // bin entries a lane fetches together
 
 // Linear value -> sRGB8 code = number of thresholds <= x (thr[255] = +inf).  The hardware
 // log2/exp2 give a candidate within one code of the answer; two table compares make it exact, so
@@ -259,6 +260,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile = blockIdx.x;
+#define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
+    SXE_STAMP(0);
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
     const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
     for (int i = tid; i < kTilePixels; i += kRasterThreads) vis[i] = kVisEmpty;
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     if (tid < kTexCache && (uint32_t)tid < a.n_textures) s_tex[tid] = a.textures[tid];
     if (tid == 0) { s_nwq = 0; s_ncov = 0; }
     __syncthreads();
+    SXE_STAMP(1);
 
     // rectangle of this tile that exists in the frame and the scissor (inclusive)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
@@ -277,17 +281,30 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     // two passes over the bin: the front part holds small boxes, the back part the others
     for (int part = 0; part < 2; ++part) {
         const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
-        for (uint32_t base = lo + (uint32_t)wave * 64u; base < hi; base += kRasterThreads) {
-            const uint32_t e = base + (uint32_t)lane;
-            const bool valid = e < hi;
+        // a wave takes kEntriesPerLane * 64 consecutive entries per round: all their slot numbers
+        // are loaded together, then all their records, so a round costs two memory round trips
+        for (uint32_t base = lo; base < hi; base += kRasterThreads * kEntriesPerLane) {
+          uint32_t slots[kEntriesPerLane];
+          RastRec recs[kEntriesPerLane];
+#pragma unroll
+          for (int k = 0; k < kEntriesPerLane; ++k) {
+              const uint32_t e = base + (uint32_t)(kRasterThreads * k + tid);
+              slots[k] = e < hi ? a.bins[off + e] : 0xFFFFFFFFu;
+          }
+#pragma unroll
+          for (int k = 0; k < kEntriesPerLane; ++k) {
+              recs[k].x0 = kNoRaster;
+              if (slots[k] != 0xFFFFFFFFu) recs[k] = a.rast[slots[k]];
+          }
+#pragma unroll
+          for (int k = 0; k < kEntriesPerLane; ++k) {
+            const bool valid = slots[k] != 0xFFFFFFFFu;
             bool wide_box = false;
-            RastRec r;
-            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
+            const RastRec r = recs[k];
             Tri t = {0, 0, 0, 0, 0, 0};
             int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
             if (valid) {
-                const uint32_t slot = a.bins[off + e];
-                r = a.rast[slot];
+                const uint32_t slot = slots[k];
                 t = unpack_tri(r, a.wide, slot);
                 const bool nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
                 const bool alone = nonempty && (bx1 - bx0 + 1) * (by1 - by0 + 1) <= kLaneBox && narrow(t);
@@ -318,9 +335,12 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                     raster_wide(vis, src, ws, t, r, (uint32_t)lane, 64u, tpx, tpy);
                 }
             }
+          }
         }
     }
+    SXE_STAMP(2);
     __syncthreads();
+    SXE_STAMP(3);
     {
         // every wave loads the queued triangles and takes every fourth 64-pixel step of each
         const uint32_t nq = min(s_nwq, (uint32_t)kWideQueue);
@@ -347,7 +367,11 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
         }
     }
     __syncthreads();
-    if (a.debug & kDebugSkipResolve) return;
+    SXE_STAMP(4);
+    if (a.debug & kDebugSkipResolve) {
+        SXE_STAMP(7);
+        return;
+    }
 
     // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target.
     // A thread owns kTilePixels / kRasterThreads pixels and handles them kResolveBatch at a time,
@@ -377,6 +401,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
         }
     }
     __syncthreads();
+    SXE_STAMP(5);
     const uint32_t n_cov = s_ncov;
     for (uint32_t q0 = (uint32_t)tid; q0 < n_cov; q0 += kRasterThreads * kResolveBatch) {
         bool live[kResolveBatch], cov[kResolveBatch];
@@ -495,6 +520,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                 if (COVERAGE) a.out_prim[p] = prim[b];
             }
     }
+    SXE_STAMP(7);
 }
 
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
