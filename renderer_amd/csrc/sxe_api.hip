@@ -84,7 +84,7 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, tile_counters /* count | fill front | fill back */, tile_off, bins, object_mesh;
+    DevBuf<uint32_t> blk_count, tile_counters /* count | fill front | fill back | launch order */, tile_off, bins, object_mesh, bin_keys;
     DevBuf<uint8_t> visible;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
@@ -180,6 +180,7 @@ hipError_t reserve_records(sxe_ctx *c)
     if ((e = c->rast.reserve(n)) != hipSuccess) return e;
     if ((e = c->wide.reserve(n)) != hipSuccess) return e;
     if ((e = c->shade.reserve(n)) != hipSuccess) return e;
+    if ((e = c->bin_keys.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if (c->cfg.shading != SXE_SHADE_TEXTURE && (e = c->color.reserve(n)) != hipSuccess) return e;
     return c->clip_list.reserve(c->fan_capacity);
 }
@@ -247,6 +248,21 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ho[a].texture < ho[b].texture; });
 
+    // vertex range touched by every run of 256 triangles of every mesh (mesh-local indices)
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ranges(hm.size());
+    for (size_t m = 0; m < hm.size(); ++m) {
+        const uint32_t nt = meshes[m].n_tri;
+        for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) {
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            const uint32_t t1 = std::min(nt, t0 + (uint32_t)kSetupThreads);
+            for (uint32_t k = 3 * t0; k < 3 * t1; ++k) {
+                lo = std::min(lo, hm[m].idx[k]);
+                hi = std::max(hi, hm[m].idx[k]);
+            }
+            ranges[m].push_back({lo, hi - lo + 1u});
+        }
+    }
+
     std::vector<InstDev> insts(order.size());
     std::vector<BlockDesc> blocks;
     uint64_t prims = 0;
@@ -257,7 +273,11 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
         insts[d].texture = o.texture;
         insts[d].prim_base = (uint32_t)prims;
         const uint32_t nt = meshes[o.mesh].n_tri;
-        for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) blocks.push_back({(uint32_t)d, t0});
+        for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) {
+            const auto &vr = ranges[o.mesh][t0 / kSetupThreads];
+            blocks.push_back({(uint32_t)d, t0, vr.first, vr.second, order[d], meshes[o.mesh].vtx_base, meshes[o.mesh].idx_base,
+                              nt, o.texture, (uint32_t)prims, 0u, 0u});
+        }
         prims += nt;
         if (prims > SXE_MAX_PRIMS) return fail(c, SXE_E_CAPACITY, "more than %u triangles per frame", SXE_MAX_PRIMS);
         // record slots are 32-bit: 256 per work item plus the region for clipped fans
@@ -363,6 +383,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sa.visible = c->visible.p;
     sa.n_blocks = c->n_blocks;
     sa.shading = c->cfg.shading;
+    sa.debug = c->cfg.flags & kDebugMask;
     sa.g = c->g;
     sa.blk_count = c->blk_count.p;
     sa.tile_count = c->tile_counters.p;
@@ -372,6 +393,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sa.color = c->color.p;
     sa.fan_capacity = (uint32_t)c->fan_capacity;
     sa.clip_list = c->clip_list.p;
+    sa.bin_keys = c->bin_keys.p;
     sa.counters = c->counters.p;
     SXE_HIP(c, launch_setup(sa, s));
     SXE_HIP(c, launch_clip(sa, s));
@@ -382,6 +404,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sc.n_blocks = c->n_blocks;
     sc.tile_count = sa.tile_count;
     sc.tile_off = c->tile_off.p;
+    sc.tile_order = c->tile_counters.p + 3 * ntc;
     sc.n_tiles = nt;
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
     sc.counters = c->counters.p;
@@ -395,6 +418,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ba.fan_blocks = (uint32_t)((c->fan_capacity + kSetupThreads - 1) / kSetupThreads);
     ba.rast = c->rast.p;
     ba.wide = c->wide.p;
+    ba.bin_keys = c->bin_keys.p;
     ba.tile_count = sa.tile_count;
     ba.tile_off = c->tile_off.p;
     ba.fill_front = c->tile_counters.p + ntc;
@@ -409,6 +433,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ra.tile_count = sa.tile_count;
     ra.tile_off = c->tile_off.p;
     ra.fill_front = ba.fill_front;
+    ra.tile_order = sc.tile_order;
     ra.bins = c->bins.p;
     ra.rast = c->rast.p;
     ra.wide = c->wide.p;
@@ -550,7 +575,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(3 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_counters.reserve(4 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_off.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile offsets)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
@@ -568,7 +593,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->pvm.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->visible.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->visible.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release(); c->bin_keys.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
@@ -768,6 +793,12 @@ int sxe_sync(sxe_ctx *c)
     if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
         fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", c->h_counters->pad[0],
                 c->h_counters->pad[1], c->h_counters->pad[2], c->h_counters->clip_count, c->h_counters->fan_records);
+    if ((c->cfg.flags & kDebugTileTimes) && getenv("SXE_DEBUG_COUNTERS")) {
+        const uint32_t *p = c->h_counters->pad;
+        const double w = p[8] ? (double)p[8] : 1.0;
+        fprintf(stderr, "[sxe] k_setup: %u working waves; mean ticks (10 ns) per wave: load+vertex %.1f, triangle %.1f, rank %.1f, "
+                        "records %.1f, count+clip %.1f\n", p[8], p[3] / w, p[4] / w, p[5] / w, p[6] / w, p[7] / w);
+    }
     if (c->cfg.flags & SXE_FLAG_TIMING) {
         float ms[EV_N] = {};
         for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i - 1], c->ev[i]));

@@ -78,22 +78,48 @@ __device__ inline bool narrow(const Tri &t)
 // "inside" is E - bias >= 0 with bias 0 on those edges and 1 on the others.
 __device__ inline int32_t edge_bias(int32_t ex, int32_t ey) { return (ey < 0 || (ey == 0 && ex > 0)) ? 0 : 1; }
 
+// Product of two values that fit 24 signed bits (v_mul_i32_i24 runs at full rate, the general
+// 32-bit multiply at a quarter of it).  Edge vectors and sample offsets of a narrow triangle are
+// below 2^15 in magnitude, so their products are exact.
+__device__ inline int32_t mul_narrow(int32_t a, int32_t b) { return __mul24(a, b); }
+
+// Biased edge functions of a narrow triangle at the centre of pixel (i, j) of its own box:
+// the sample is inside when all three are >= 0.
+struct EdgeStart {
+    int32_t ex0, ey0, ex1, ey1, ex2, ey2;
+    int32_t b1, b2;
+    int32_t R0, R1, R2;
+};
+
+__device__ inline EdgeStart edge_start(const Tri &t, int32_t i, int32_t j)
+{
+    EdgeStart e;
+    e.ex0 = t.x2 - t.x1; e.ey0 = t.y2 - t.y1;
+    e.ex1 = t.x0 - t.x2; e.ey1 = t.y0 - t.y2;
+    e.ex2 = t.x1 - t.x0; e.ey2 = t.y1 - t.y0;
+    e.b1 = edge_bias(e.ex1, e.ey1);
+    e.b2 = edge_bias(e.ex2, e.ey2);
+    const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
+    e.R0 = mul_narrow(e.ex0, sy - t.y1) - mul_narrow(e.ey0, sx - t.x1) - edge_bias(e.ex0, e.ey0);
+    e.R1 = mul_narrow(e.ex1, sy - t.y2) - mul_narrow(e.ey1, sx - t.x2) - e.b1;
+    e.R2 = mul_narrow(e.ex2, sy - t.y0) - mul_narrow(e.ey2, sx - t.x0) - e.b2;
+    return e;
+}
+
 // Does a narrow triangle cover at least one sample of its (small) pixel box?
 __device__ inline bool covers_any(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
 {
-    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
-    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
-    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-    const int32_t b0 = edge_bias(ex0, ey0), b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
+    const EdgeStart e = edge_start(t, bx0, by0);
+    int32_t R0 = e.R0, R1 = e.R1, R2 = e.R2;
     bool any = false;
-    for (int32_t j = by0; j <= by1; ++j)
+    for (int32_t j = by0; j <= by1; ++j) {
+        int32_t E0 = R0, E1 = R1, E2 = R2;
         for (int32_t i = bx0; i <= bx1; ++i) {
-            const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
-            const int32_t E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - b0;
-            const int32_t E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
-            const int32_t E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
             any = any || ((E0 | E1 | E2) >= 0);
+            E0 -= 256 * e.ey0; E1 -= 256 * e.ey1; E2 -= 256 * e.ey2; // one pixel to the right
         }
+        R0 += 256 * e.ex0; R1 += 256 * e.ex1; R2 += 256 * e.ex2;     // one pixel down
+    }
     return any;
 }
 

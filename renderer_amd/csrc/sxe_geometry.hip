@@ -202,26 +202,58 @@ struct ScreenTri {
     bool swapped;               // corners 1 and 2 were exchanged
 };
 
-// Perspective divide, viewport map, snap, orientation, bounding box.  False = nothing to draw.
-__device__ inline bool setup_screen_tri(const float4 &c0, const float4 &c1, const float4 &c2, const FrameGeom &g,
+// Everything about one projected vertex that does not depend on the triangle it is used in.
+struct PVert {
+    int32_t x, y;   // window position, 24.8 fixed point
+    float zn, rw;   // z/w and 1/w
+    uint32_t mask;  // kOut* bits
+};
+// bits 0-5: outside a plane of the view volume (near, far, -x, +x, -y, +y); bits 6-9: outside a
+// guard-band plane; bit 10: cannot be projected (w <= 0 or far outside the fixed-point range)
+constexpr uint32_t kOutVolume = 0x3Fu, kOutGuard = 0x3C3u, kOutUnusable = 0x400u;
+
+// Clip tests, perspective divide, viewport map and snap of one vertex.
+__device__ inline PVert project_vertex(const float4 &c, const FrameGeom &g)
+{
+    PVert p;
+    const float gw = kGuard * c.w;
+    uint32_t m = 0;
+    if (!(c.z >= 0.0f)) m |= 1u;
+    if (!(c.w - c.z >= 0.0f)) m |= 2u;
+    if (!(c.w + c.x >= 0.0f)) m |= 4u;
+    if (!(c.w - c.x >= 0.0f)) m |= 8u;
+    if (!(c.w + c.y >= 0.0f)) m |= 16u;
+    if (!(c.w - c.y >= 0.0f)) m |= 32u;
+    if (!(gw + c.x >= 0.0f)) m |= 64u;
+    if (!(gw - c.x >= 0.0f)) m |= 128u;
+    if (!(gw + c.y >= 0.0f)) m |= 256u;
+    if (!(gw - c.y >= 0.0f)) m |= 512u;
+    const float rw = 1.0f / c.w;
+    const float xs = ((c.x * rw + 1.0f) * g.half_w) * 256.0f, ys = ((c.y * rw + 1.0f) * g.half_h) * 256.0f;
+    const float lim = 1073741824.0f;
+    const bool usable = (c.w > 0.0f) && (fabsf(xs) <= lim) && (fabsf(ys) <= lim);
+    if (!usable) m |= kOutUnusable;
+    p.x = usable ? (int32_t)rintf(xs) : 0;
+    p.y = usable ? (int32_t)rintf(ys) : 0;
+    p.zn = c.z * rw;
+    p.rw = rw;
+    p.mask = m;
+    return p;
+}
+
+// Orientation and bounding box of a triangle of projected vertices.  False = nothing to draw.
+__device__ inline bool setup_screen_tri(const PVert &v0, const PVert &v1, const PVert &v2, const FrameGeom &g,
                                         ScreenTri &s)
 {
-    if (!(c0.w > 0.0f) || !(c1.w > 0.0f) || !(c2.w > 0.0f)) return false;
-    const float rw0 = 1.0f / c0.w, rw1 = 1.0f / c1.w, rw2 = 1.0f / c2.w;
-    const float xs0 = ((c0.x * rw0 + 1.0f) * g.half_w) * 256.0f, ys0 = ((c0.y * rw0 + 1.0f) * g.half_h) * 256.0f;
-    const float xs1 = ((c1.x * rw1 + 1.0f) * g.half_w) * 256.0f, ys1 = ((c1.y * rw1 + 1.0f) * g.half_h) * 256.0f;
-    const float xs2 = ((c2.x * rw2 + 1.0f) * g.half_w) * 256.0f, ys2 = ((c2.y * rw2 + 1.0f) * g.half_h) * 256.0f;
-    const float lim = 1073741824.0f;
-    if (!(fabsf(xs0) <= lim) || !(fabsf(ys0) <= lim) || !(fabsf(xs1) <= lim) || !(fabsf(ys1) <= lim) ||
-        !(fabsf(xs2) <= lim) || !(fabsf(ys2) <= lim))
-        return false;
+    if ((v0.mask | v1.mask | v2.mask) & kOutUnusable) return false;
     Tri t;
-    t.x0 = (int32_t)rintf(xs0); t.y0 = (int32_t)rintf(ys0);
-    t.x1 = (int32_t)rintf(xs1); t.y1 = (int32_t)rintf(ys1);
-    t.x2 = (int32_t)rintf(xs2); t.y2 = (int32_t)rintf(ys2);
+    t.x0 = v0.x; t.y0 = v0.y;
+    t.x1 = v1.x; t.y1 = v1.y;
+    t.x2 = v2.x; t.y2 = v2.y;
     const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
     if (area2 == 0) return false;
-    float zn1 = c1.z * rw1, zn2 = c2.z * rw2, r1 = rw1, r2 = rw2;
+    const float rw0 = v0.rw;
+    float zn1 = v1.zn, zn2 = v2.zn, r1 = v1.rw, r2 = v2.rw;
     s.swapped = area2 < 0;
     if (s.swapped) { // no face culling (Rasterizer::FILL): reorient instead
         int32_t q;
@@ -233,7 +265,7 @@ __device__ inline bool setup_screen_tri(const float4 &c0, const float4 &c1, cons
     }
     if (!pixel_box(t, 0, (int32_t)g.width - 1, (int32_t)g.sy0, (int32_t)g.sy1 - 1, s.px0, s.px1, s.py0, s.py1)) return false;
     s.t = t;
-    s.zn0 = c0.z * rw0; s.zn1 = zn1; s.zn2 = zn2;
+    s.zn0 = v0.zn; s.zn1 = zn1; s.zn2 = zn2;
     s.rw0 = rw0; s.rw1 = r1; s.rw2 = r2;
     return true;
 }
@@ -242,27 +274,27 @@ struct Attr3 {
     float a0, a1, a2;
 };
 
-// Writes the records of one screen triangle into slot `rec`.  uv / rgb are per-corner attributes
-// in the original corner order; corners 1 and 2 are exchanged when the triangle was reoriented.
-__device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
-                                     int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
+// Builds the records of one screen triangle that belongs in slot `rec`.  u, v are the per-corner
+// texture coordinates already multiplied by the corner's 1/w, cr/cg/cb the plain per-corner
+// colours, all in the original corner order; corners 1 and 2 are exchanged when the triangle was
+// reoriented.  The two records every triangle has are returned for the caller to store; the
+// optional ones (corners that do not fit the packed form, colour planes) are stored here.
+__device__ inline void make_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
+                                    int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb, RastRec &r, ShadeRec &h)
 {
-    RastRec r;
     r.x0 = s.t.x0; r.y0 = s.t.y0;
     const int32_t dx1 = s.t.x1 - s.t.x0, dy1 = s.t.y1 - s.t.y0, dx2 = s.t.x2 - s.t.x0, dy2 = s.t.y2 - s.t.y0;
-    if (fits16(dx1) && fits16(dy1) && fits16(dx2) && fits16(dy2)) {
-        r.d1 = ((uint32_t)dx1 & 0xFFFFu) | ((uint32_t)dy1 << 16);
-        r.d2 = ((uint32_t)dx2 & 0xFFFFu) | ((uint32_t)dy2 << 16);
-    } else {
-        r.d1 = kWideTri;
-        r.d2 = 0;
+    const bool packed = fits16(dx1) && fits16(dy1) && fits16(dx2) && fits16(dy2);
+    const uint32_t d1 = ((uint32_t)dx1 & 0xFFFFu) | ((uint32_t)dy1 << 16), d2 = ((uint32_t)dx2 & 0xFFFFu) | ((uint32_t)dy2 << 16);
+    r.d1 = packed ? d1 : kWideTri;
+    r.d2 = packed ? d2 : 0u;
+    if (!packed) {
         WideRec w;
         w.x1 = s.t.x1; w.y1 = s.t.y1; w.x2 = s.t.x2; w.y2 = s.t.y2;
         a.wide[rec] = w;
     }
     r.z0 = s.zn0; r.dz1 = s.zn1 - s.zn0; r.dz2 = s.zn2 - s.zn0;
     r.order = order;
-    a.rast[rec] = r;
     if (s.swapped) {
         float t;
         t = u.a1; u.a1 = u.a2; u.a2 = t;
@@ -271,11 +303,10 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t 
         t = cg.a1; cg.a1 = cg.a2; cg.a2 = t;
         t = cb.a1; cb.a1 = cb.a2; cb.a2 = t;
     }
-    ShadeRec h;
     h.iw0 = s.rw0; h.diw1 = s.rw1 - s.rw0; h.diw2 = s.rw2 - s.rw0;
     if (a.shading != SXE_SHADE_VERTEX_COLOR) {
-        const float uw0 = u.a0 * s.rw0, uw1 = u.a1 * s.rw1, uw2 = u.a2 * s.rw2;
-        const float vw0 = v.a0 * s.rw0, vw1 = v.a1 * s.rw1, vw2 = v.a2 * s.rw2;
+        const float uw0 = u.a0, uw1 = u.a1, uw2 = u.a2;
+        const float vw0 = v.a0, vw1 = v.a1, vw2 = v.a2;
         h.uw0 = uw0; h.duw1 = uw1 - uw0; h.duw2 = uw2 - uw0;
         h.vw0 = vw0; h.dvw1 = vw1 - vw0; h.dvw2 = vw2 - vw0;
     } else {
@@ -284,7 +315,6 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t 
     h.prim = prim;
     h.fan_base = 0;
     h.tex_fan = (uint32_t)texture & 0xFFFFFFu;
-    a.shade[rec] = h;
     if (a.shading != SXE_SHADE_TEXTURE) {
         const float r0 = cr.a0 * s.rw0, r1 = cr.a1 * s.rw1, r2 = cr.a2 * s.rw2;
         const float g0 = cg.a0 * s.rw0, g1 = cg.a1 * s.rw1, g2 = cg.a2 * s.rw2;
@@ -296,6 +326,16 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t 
         c.pad0 = c.pad1 = c.pad2 = 0.0f;
         a.color[rec] = c;
     }
+}
+
+__device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
+                                     int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
+{
+    RastRec r;
+    ShadeRec h;
+    make_records(a, rec, order, s, prim, texture, u, v, cr, cg, cb, r, h);
+    a.rast[rec] = r;
+    a.shade[rec] = h;
 }
 
 // One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
@@ -311,54 +351,95 @@ __device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
 // and owns 256 consecutive record slots, which it fills from the front in submission order.  That
 // order is what makes "first primitive wins a depth tie" (Comparison::Less,
 // src/renderer/drawer.rs:700) fall out of a (depth | slot) minimum.
-__global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
+struct SetupShared {
+    uint32_t wave_tot[kSetupThreads / 64];
+    uint32_t keys[kSetupThreads];
+    union {
+        // first the projected vertices of the work item's triangles: position, (z/w, 1/w), (u/w, v/w), flags
+        struct {
+            int2 xy[kVtxCache];
+            float2 zr[kVtxCache];
+            float2 uv[kVtxCache];
+            uint32_t mask[kVtxCache];
+        } vtx;
+        // then the finished records in slot order, on their way to memory
+        uint4 stage[kSetupThreads * 3];
+    };
+};
+
+__device__ inline void setup_block(const SetupArgs &a, const uint32_t block, SetupShared &sh)
 {
-    __shared__ uint32_t s_wave_tot[kSetupThreads / 64];
+    uint32_t *s_wave_tot = sh.wave_tot;
+    int2 *s_xy = sh.vtx.xy;
+    float2 *s_zr = sh.vtx.zr, *s_uv = sh.vtx.uv;
+    uint32_t *s_mask = sh.vtx.mask;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BlockDesc bd = a.blocks[blockIdx.x];
-    const InstDev inst = a.insts[bd.inst];
-    if (!a.visible[inst.object]) {
-        if (tid == 0) a.blk_count[blockIdx.x] = 0;
+    const BlockDesc bd = a.blocks[block];
+    if (!a.visible[bd.object]) {
+        if (tid == 0) a.blk_count[block] = 0;
         return;
     }
-    const MeshDev mesh = a.meshes[inst.mesh];
-    const float *pvm = a.pvm + 16 * (size_t)inst.object;
+    const float *pvm = a.pvm + 16 * (size_t)bd.object;
     const uint32_t t = bd.tri_start + tid;
-    const bool valid = t < mesh.n_tri;
+    const bool valid = t < bd.n_tri;
+
+    // Triangles that are neighbours in the index list share most of their vertices: when the
+    // vertex range of these 256 triangles fits the cache, every vertex is projected once.
+    const bool cached = bd.vtx_n <= (uint32_t)kVtxCache;
+    if (cached) {
+        for (uint32_t i = (uint32_t)tid; i < bd.vtx_n; i += kSetupThreads) {
+            const sxe_vertex &w = a.vertices[bd.vtx_base + bd.vtx_lo + i];
+            const PVert p = project_vertex(transform_vertex(pvm, w.pos[0], w.pos[1], w.pos[2]), a.g);
+            s_xy[i] = make_int2(p.x, p.y);
+            s_zr[i] = make_float2(p.zn, p.rw);
+            s_uv[i] = make_float2(w.uv[0] * p.rw, w.uv[1] * p.rw);
+            s_mask[i] = p.mask;
+        }
+        __syncthreads();
+    }
+    if (a.debug & kDebugSkipRaster) { // development: stop after the vertex phase
+        if (tid == 0) a.blk_count[block] = 0;
+        return;
+    }
 
     enum { CULLED = 0, FAST = 1, CLIP = 2 };
     int state = CULLED;
     uint32_t vi0 = 0, vi1 = 0, vi2 = 0;
     ScreenTri st;
     st.px0 = st.px1 = st.py0 = st.py1 = 0;
+    Attr3 uw = {0, 0, 0}, vw = {0, 0, 0};
 
     if (valid) {
-        const uint32_t *ip = a.indices + mesh.idx_base + 3 * (size_t)t;
-        vi0 = mesh.vtx_base + ip[0];
-        vi1 = mesh.vtx_base + ip[1];
-        vi2 = mesh.vtx_base + ip[2];
-        const float *p0 = a.vertices[vi0].pos, *p1 = a.vertices[vi1].pos, *p2 = a.vertices[vi2].pos;
-        const float4 c0 = transform_vertex(pvm, p0[0], p0[1], p0[2]);
-        const float4 c1 = transform_vertex(pvm, p1[0], p1[1], p1[2]);
-        const float4 c2 = transform_vertex(pvm, p2[0], p2[1], p2[2]);
+        const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
+        const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+        vi0 = bd.vtx_base + i0;
+        vi1 = bd.vtx_base + i1;
+        vi2 = bd.vtx_base + i2;
+        PVert v0, v1, v2;
+        if (cached) {
+            const uint32_t k0 = i0 - bd.vtx_lo, k1 = i1 - bd.vtx_lo, k2 = i2 - bd.vtx_lo;
+            const int2 q0 = s_xy[k0], q1 = s_xy[k1], q2 = s_xy[k2];
+            const float2 z0 = s_zr[k0], z1 = s_zr[k1], z2 = s_zr[k2];
+            const float2 t0 = s_uv[k0], t1 = s_uv[k1], t2 = s_uv[k2];
+            v0 = {q0.x, q0.y, z0.x, z0.y, s_mask[k0]};
+            v1 = {q1.x, q1.y, z1.x, z1.y, s_mask[k1]};
+            v2 = {q2.x, q2.y, z2.x, z2.y, s_mask[k2]};
+            uw = {t0.x, t1.x, t2.x};
+            vw = {t0.y, t1.y, t2.y};
+        } else {
+            const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
+            v0 = project_vertex(transform_vertex(pvm, w0.pos[0], w0.pos[1], w0.pos[2]), a.g);
+            v1 = project_vertex(transform_vertex(pvm, w1.pos[0], w1.pos[1], w1.pos[2]), a.g);
+            v2 = project_vertex(transform_vertex(pvm, w2.pos[0], w2.pos[1], w2.pos[2]), a.g);
+            uw = {w0.uv[0] * v0.rw, w1.uv[0] * v1.rw, w2.uv[0] * v2.rw};
+            vw = {w0.uv[1] * v0.rw, w1.uv[1] * v1.rw, w2.uv[1] * v2.rw};
+        }
         // all three corners outside one plane of the view volume -> nothing visible
-        const bool rej =
-            (!(c0.z >= 0.0f) && !(c1.z >= 0.0f) && !(c2.z >= 0.0f)) ||
-            (!(c0.w - c0.z >= 0.0f) && !(c1.w - c1.z >= 0.0f) && !(c2.w - c2.z >= 0.0f)) ||
-            (!(c0.w + c0.x >= 0.0f) && !(c1.w + c1.x >= 0.0f) && !(c2.w + c2.x >= 0.0f)) ||
-            (!(c0.w - c0.x >= 0.0f) && !(c1.w - c1.x >= 0.0f) && !(c2.w - c2.x >= 0.0f)) ||
-            (!(c0.w + c0.y >= 0.0f) && !(c1.w + c1.y >= 0.0f) && !(c2.w + c2.y >= 0.0f)) ||
-            (!(c0.w - c0.y >= 0.0f) && !(c1.w - c1.y >= 0.0f) && !(c2.w - c2.y >= 0.0f));
+        const bool rej = (v0.mask & v1.mask & v2.mask & kOutVolume) != 0;
         if (!rej) {
-            bool inside = true;
-            const float4 cs[3] = {c0, c1, c2};
-            for (int k = 0; k < 3; ++k) {
-                const float gw = kGuard * cs[k].w;
-                inside = inside && (cs[k].z >= 0.0f) && (cs[k].w - cs[k].z >= 0.0f) && (gw + cs[k].x >= 0.0f) &&
-                         (gw - cs[k].x >= 0.0f) && (gw + cs[k].y >= 0.0f) && (gw - cs[k].y >= 0.0f);
-            }
+            const bool inside = ((v0.mask | v1.mask | v2.mask) & kOutGuard) == 0;
             if (inside) {
-                if (setup_screen_tri(c0, c1, c2, a.g, st)) {
+                if (setup_screen_tri(v0, v1, v2, a.g, st)) {
                     state = FAST;
                     // a triangle whose box holds a few pixels and contains none of their samples draws nothing
                     const int32_t bw = st.px1 - st.px0 + 1, bh = st.py1 - st.py0 + 1;
@@ -381,25 +462,56 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
         if (w < wave) wave_base += v;
         total += v;
     }
-    if (tid == 0) a.blk_count[blockIdx.x] = total;
-    const uint32_t slot = blockIdx.x * kSetupThreads + wave_base + wave_rank;
-    const uint32_t prim = inst.prim_base + t;
+    if (tid == 0) a.blk_count[block] = total;
+    const uint32_t local = wave_base + wave_rank;
+    const uint32_t slot0 = block * kSetupThreads, slot = slot0 + local;
+    const uint32_t prim = bd.prim_base + t;
 
-    // ---- triangles that needed no clipping ----
+    // The records go to memory through LDS: a lane storing its own 32- and 48-byte records would
+    // send the L2 one 16-byte request per lane and instruction; laid out in slot order first, the
+    // workgroup stores them as whole cache lines.
+    RastRec r;
+    ShadeRec h;
+    r.x0 = kNoRaster; r.y0 = 0; r.d1 = 0; r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = slot;
+    h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
+    h.prim = prim; h.fan_base = 0; h.tex_fan = 0; // k_clip fills in the slot of a clipped triangle
     if (state == FAST) {
-        const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
-        Attr3 u = {w0.uv[0], w1.uv[0], w2.uv[0]}, v = {w0.uv[1], w1.uv[1], w2.uv[1]};
         Attr3 cr = {0, 0, 0}, cg = {0, 0, 0}, cb = {0, 0, 0};
         if (a.shading != SXE_SHADE_TEXTURE) {
+            const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
             cr = {w0.color[0], w1.color[0], w2.color[0]};
             cg = {w0.color[1], w1.color[1], w2.color[1]};
             cb = {w0.color[2], w1.color[2], w2.color[2]};
         }
-        write_records(a, slot, slot, st, prim, inst.texture, u, v, cr, cg, cb);
+        make_records(a, slot, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
     }
     const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
     const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
     const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
+    // (the rank barrier above came after the last read of the vertex arrays, which `stage` overlays)
+    if (state != CULLED) {
+        const bool big = (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kSmallBox;
+        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 2u + (big ? 1u : 0u) : kBinKeyFromRecord);
+        sh.stage[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
+        sh.stage[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), r.order);
+    }
+    __syncthreads();
+    if ((uint32_t)tid < total) a.bin_keys[slot0 + tid] = sh.keys[tid];
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.rast + slot0);
+        for (uint32_t c = (uint32_t)tid; c < 2u * total; c += kSetupThreads) dst[c] = sh.stage[c];
+    }
+    __syncthreads();
+    if (state != CULLED) {
+        sh.stage[3 * local] = make_uint4(__float_as_uint(h.iw0), __float_as_uint(h.diw1), __float_as_uint(h.diw2), __float_as_uint(h.uw0));
+        sh.stage[3 * local + 1] = make_uint4(__float_as_uint(h.duw1), __float_as_uint(h.duw2), __float_as_uint(h.vw0), __float_as_uint(h.dvw1));
+        sh.stage[3 * local + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_base, h.tex_fan);
+    }
+    __syncthreads();
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.shade + slot0);
+        for (uint32_t c = (uint32_t)tid; c < 3u * total; c += kSetupThreads) dst[c] = sh.stage[c];
+    }
     // wave-aggregated tile counting: one atomic per distinct tile per wave
     unsigned long long pending = __ballot(single);
     while (pending) {
@@ -414,9 +526,6 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
     // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
     // order) and are queued for k_clip ----
     if (state == CLIP) {
-        RastRec none;
-        none.x0 = kNoRaster; none.y0 = 0; none.d1 = 0; none.d2 = 0; none.z0 = none.dz1 = none.dz2 = 0.0f; none.order = slot;
-        a.rast[slot] = none;
         const uint32_t at = atomicAdd(&a.counters->clip_count, 1u);
         if (at < a.fan_capacity) {
             ClipItem it;
@@ -425,6 +534,18 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
         } else {
             atomicOr(&a.counters->overflow, kOverflowClip);
         }
+    }
+}
+
+constexpr uint32_t kBlocksPerGroup = 1; // work items one setup workgroup takes, one after the other
+
+__global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
+{
+    __shared__ SetupShared sh;
+    const uint32_t first = blockIdx.x * kBlocksPerGroup, last = min(first + kBlocksPerGroup, a.n_blocks);
+    for (uint32_t block = first; block < last; ++block) {
+        setup_block(a, block, sh);
+        __syncthreads(); // the next work item overwrites the shared arrays
     }
 }
 
@@ -469,12 +590,14 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         const ClipVert &q0 = poly[0], &q1 = poly[f + 1], &q2 = poly[f + 2];
         const uint32_t rec = h.fan_base + f;
         ScreenTri s2;
-        if (!setup_screen_tri(make_float4(q0.c[0], q0.c[1], q0.c[2], q0.c[3]), make_float4(q1.c[0], q1.c[1], q1.c[2], q1.c[3]),
-                              make_float4(q2.c[0], q2.c[1], q2.c[2], q2.c[3]), a.g, s2)) {
+        const PVert v0 = project_vertex(make_float4(q0.c[0], q0.c[1], q0.c[2], q0.c[3]), a.g);
+        const PVert v1 = project_vertex(make_float4(q1.c[0], q1.c[1], q1.c[2], q1.c[3]), a.g);
+        const PVert v2 = project_vertex(make_float4(q2.c[0], q2.c[1], q2.c[2], q2.c[3]), a.g);
+        if (!setup_screen_tri(v0, v1, v2, a.g, s2)) {
             a.rast[rec] = none;
             continue;
         }
-        Attr3 u = {q0.c[4], q1.c[4], q2.c[4]}, v = {q0.c[5], q1.c[5], q2.c[5]};
+        Attr3 u = {q0.c[4] * v0.rw, q1.c[4] * v1.rw, q2.c[4] * v2.rw}, v = {q0.c[5] * v0.rw, q1.c[5] * v1.rw, q2.c[5] * v2.rw};
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
         write_records(a, rec, slot, s2, prim, inst.texture, u, v, cr, cg, cb);
         count_box(a, s2);
@@ -494,13 +617,38 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
+constexpr int kOrderClasses = 128;
+__device__ inline uint32_t order_class(uint32_t count) { return min((count + 15u) >> 4, (uint32_t)kOrderClasses - 1u); }
+
 // Workgroup 0: exclusive scan of the per-tile bin counts (eight counts per thread and round).
 // Workgroup 1: total number of surviving triangles.
+// Workgroup 2: launch order of the tiles.
 __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 {
     __shared__ uint32_t s_part[16];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 2) {
+        // launch order of the tile workgroups: a counting sort by bin size class, fullest first,
+        // so that the long-running tiles start early and the short ones fill the end of the launch
+        __shared__ uint32_t s_hist[kOrderClasses];
+        if (tid < kOrderClasses) s_hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(a.tile_count[i])], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int k = kOrderClasses - 1; k >= 0; --k) {
+                const uint32_t h = s_hist[k];
+                s_hist[k] = run;
+                run += h;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < a.n_tiles; i += 1024)
+            a.tile_order[atomicAdd(&s_hist[order_class(a.tile_count[i])], 1u)] = i;
+        return;
+    }
     if (blockIdx.x == 1) {
         uint32_t sum = 0;
         for (uint32_t i = tid; i < a.n_blocks; i += 1024) sum += a.blk_count[i];
@@ -557,39 +705,11 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // whose pixel box inside the tile holds at most kSmallBox pixels are stored from the front of the
 // tile's range, the others from its back, so that the raster kernel meets boxes of similar size
 // next to each other.  The order of entries inside a bin is irrelevant to the image.
-__global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
+// One round of a wave: lane l files record `rec` under `key` (a kBinKey* value or 2 * tile + class).
+__device__ inline void bin_round(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, int lane)
 {
-    if (a.counters->overflow) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    uint32_t rec;
-    bool valid;
-    if (blockIdx.x < a.n_blocks) {
-        const uint32_t cnt = a.blk_count[blockIdx.x];
-        if (cnt == 0) return;
-        valid = (uint32_t)tid < cnt;
-        rec = blockIdx.x * kSetupThreads + tid;
-    } else {
-        const uint32_t first = (blockIdx.x - a.n_blocks) * kSetupThreads;
-        const uint32_t n_fan = a.counters->fan_records;
-        if (first >= n_fan) return;
-        valid = first + tid < n_fan;
-        rec = a.n_blocks * kSetupThreads + first + tid;
-    }
-    Tri t = {0, 0, 0, 0, 0, 0};
-    int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-    if (valid) {
-        const RastRec r = a.rast[rec];
-        valid = r.x0 != kNoRaster;
-        if (valid) {
-            t = unpack_tri(r, a.wide, rec);
-            valid = pixel_box(t, 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1);
-        }
-    }
-    const int32_t tx0 = bx0 / kTile, tx1 = bx1 / kTile, ty0 = by0 / kTile, ty1 = by1 / kTile;
-    const bool single = valid && tx0 == tx1 && ty0 == ty1;
-    const bool big = (bx1 - bx0 + 1) * (by1 - by0 + 1) > kSmallBox;
-    const uint32_t tile = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
-    const uint32_t key = single ? (tile * 2u + (big ? 1u : 0u)) : 0xFFFFFFFFu;
+    const bool single = valid && key < kBinKeyNone;
+    const uint32_t tile = key >> 1;
     // group the lanes of the wave by (tile, class) without touching memory ...
     unsigned long long pending = __ballot(single);
     int my_leader = lane;
@@ -615,7 +735,13 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
         const uint32_t off = a.tile_off[tile];
         a.bins[(key & 1u) ? off + a.tile_count[tile] - 1u - p : off + p] = rec;
     }
-    if (valid && !single) {
+    if (valid && key == kBinKeyFromRecord) {
+        const RastRec r = a.rast[rec];
+        if (r.x0 == kNoRaster) return;
+        const Tri t = unpack_tri(r, a.wide, rec);
+        int32_t bx0, bx1, by0, by1;
+        if (!pixel_box(t, 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1)) return;
+        const int32_t tx0 = bx0 / kTile, tx1 = bx1 / kTile, ty0 = by0 / kTile, ty1 = by1 / kTile;
         for (int32_t ty = ty0; ty <= ty1; ++ty)
             for (int32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t tl = (uint32_t)(ty - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx;
@@ -630,6 +756,40 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
                     a.bins[off + p] = rec;
                 }
             }
+    }
+}
+
+// A wave files the survivors of one setup work item (their keys were written by k_setup); the
+// workgroups past the last work item take the fan triangles of clipped primitives, whose tiles
+// are derived from their records.
+__global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
+{
+    if (a.counters->overflow) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;
+    if (blockIdx.x < seg_groups) {
+        const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+        if (seg >= a.n_blocks) return;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blk_count[seg]);
+        if (cnt == 0) return;
+        // all keys of the segment are requested before the first one is used
+        uint32_t keys[kSetupThreads / 64];
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k) {
+            const uint32_t i = 64u * k + (uint32_t)lane;
+            keys[k] = i < cnt ? a.bin_keys[seg * kSetupThreads + i] : kBinKeyNone;
+        }
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k) {
+            if (64u * k >= cnt) break;
+            const uint32_t i = 64u * k + (uint32_t)lane;
+            bin_round(a, i < cnt, seg * kSetupThreads + i, keys[k], lane);
+        }
+    } else {
+        const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
+        const uint32_t n_fan = a.counters->fan_records;
+        if (first >= n_fan) return;
+        bin_round(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, lane);
     }
 }
 
@@ -670,7 +830,7 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_setup, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+    hipLaunchKernelGGL(k_setup, dim3((a.n_blocks + kBlocksPerGroup - 1) / kBlocksPerGroup), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -684,14 +844,14 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s)
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_scan, dim3(3), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_bin(const BinArgs &a, hipStream_t s)
 {
     if (a.n_blocks + a.fan_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bin, dim3(a.n_blocks + a.fan_blocks), dim3(kSetupThreads), 0, s, a);
+    hipLaunchKernelGGL(k_bin, dim3((a.n_blocks + 3u) / 4u + a.fan_blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 

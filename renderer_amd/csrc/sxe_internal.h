@@ -43,9 +43,17 @@ struct InstDev {
     uint32_t prim_base; // id of this object's first triangle in the frame
 };
 
-struct BlockDesc { // work item of the setup kernel: 256 consecutive triangles of one object
+// Work item of the setup kernel: 256 consecutive triangles of one object.  It repeats what the
+// kernel needs from the object's InstDev and MeshDev so that a workgroup starts with one load
+// instead of a chain of three.
+struct __attribute__((aligned(16))) BlockDesc {
     uint32_t inst, tri_start;
+    uint32_t vtx_lo, vtx_n; // range of mesh-local vertex indices those triangles use
+    uint32_t object, vtx_base, idx_base, n_tri;
+    int32_t texture;
+    uint32_t prim_base, pad0, pad1;
 };
+constexpr int kVtxCache = 512; // vertices a setup workgroup can project once and share through LDS
 
 struct VBlockDesc { // work item of the vertex kernel: up to 1024 consecutive vertices of one object
     uint32_t object, vtx_start, mesh, clip_base;
@@ -99,7 +107,7 @@ struct FrameCounters {
     uint32_t fan_records;   // fan triangles of clipped primitives
     uint32_t overflow;      // kOverflow* bits
     uint32_t clip_count;    // triangles handed to the clip kernel
-    uint32_t pad[3];
+    uint32_t pad[11];       // development counters (box census, phase clocks)
 };
 
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
@@ -136,6 +144,7 @@ struct SetupArgs {
     const uint8_t *visible;
     uint32_t n_blocks;
     uint32_t shading;
+    uint32_t debug;            // kDebug* switches (development only)
     FrameGeom g;
     uint32_t *blk_count;       // survivors per workgroup
     uint32_t *tile_count;
@@ -145,14 +154,21 @@ struct SetupArgs {
     ColorRec *color;
     uint32_t fan_capacity;     // records available past slot 256 * n_blocks; also the clip list's length
     ClipItem *clip_list;
+    uint32_t *bin_keys;        // per order slot: where k_bin files the triangle (kBinKey*)
     FrameCounters *counters;
 };
+
+// Bin keys: 2 * tile + (1 if the pixel box holds more than kSmallBox pixels) for a triangle whose
+// box lies in one tile; the two values below otherwise.
+constexpr uint32_t kBinKeyFromRecord = 0xFFFFFFFFu; // several tiles: k_bin derives them from the record
+constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a clipped triangle
 
 struct ScanArgs {
     const uint32_t *blk_count;
     uint32_t n_blocks;
     const uint32_t *tile_count;
     uint32_t *tile_off;
+    uint32_t *tile_order;      // tiles in launch order: fullest bins first
     uint32_t n_tiles;
     uint32_t bin_capacity;
     FrameCounters *counters;
@@ -165,9 +181,10 @@ struct BinArgs {
     uint32_t fan_blocks;       // workgroups launched for the fan region
     const RastRec *rast;
     const WideRec *wide;
+    const uint32_t *bin_keys;
     const uint32_t *tile_count;
     const uint32_t *tile_off;
-    uint32_t *fill_front;      // per tile: entries with small pixel boxes, filled upwards
+    uint32_t *fill_front;     // per tile: entries with small pixel boxes, filled upwards
     uint32_t *fill_back;       // per tile: the others, filled downwards from the end of the bin
     uint32_t *bins;
     const FrameCounters *counters;
@@ -178,6 +195,7 @@ struct RasterArgs {
     const uint32_t *tile_count;
     const uint32_t *tile_off;
     const uint32_t *fill_front;
+    const uint32_t *tile_order; // workgroup b renders tile tile_order[b]
     const uint32_t *bins;
     const RastRec *rast;
     const WideRec *wide;

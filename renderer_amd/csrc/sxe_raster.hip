@@ -92,24 +92,20 @@ __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
     return q;
 }
 
-// sRGB decode of every texel before filtering; alpha is linear.
+// sRGB decode of every texel before filtering.  Only the colour channels: every texel's alpha is
+// 255 (the texture upload rejects anything else), and filtering four ones gives exactly one.
 __device__ inline void filter_quad(const float *dec, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, float ax,
                                    float ay, float out[4])
 {
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 3; ++k) {
         const int sh = 8 * k;
-        float c00, c10, c01, c11;
-        if (k < 3) {
-            c00 = dec[(t00 >> sh) & 255]; c10 = dec[(t10 >> sh) & 255];
-            c01 = dec[(t01 >> sh) & 255]; c11 = dec[(t11 >> sh) & 255];
-        } else {
-            c00 = c_unorm8[(t00 >> sh) & 255]; c10 = c_unorm8[(t10 >> sh) & 255];
-            c01 = c_unorm8[(t01 >> sh) & 255]; c11 = c_unorm8[(t11 >> sh) & 255];
-        }
+        const float c00 = dec[(t00 >> sh) & 255], c10 = dec[(t10 >> sh) & 255];
+        const float c01 = dec[(t01 >> sh) & 255], c11 = dec[(t11 >> sh) & 255];
         const float top = c00 + ax * (c10 - c00);
         const float bot = c01 + ax * (c11 - c01);
         out[k] = top + ay * (bot - top);
     }
+    out[3] = 1.0f;
 }
 
 __device__ inline float clamp_depth(float z)
@@ -131,21 +127,16 @@ __device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint
 __device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
                                    int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
 {
-    // every difference below is < 2^14 and every product < 2^28: exact in 32 bits
-    const int32_t ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1;
-    const int32_t ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2;
-    const int32_t ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-    const int32_t b1 = edge_bias(ex1, ey1), b2 = edge_bias(ex2, ey2);
-    const float rA = 1.0f / (float)(ex2 * (t.y2 - t.y0) - (t.x2 - t.x0) * ey2);
-    const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
-    int32_t R0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1) - edge_bias(ex0, ey0);
-    int32_t R1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2) - b1;
-    int32_t R2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0) - b2;
-    const int32_t ax0 = -256 * ey0, ax1 = -256 * ey1, ax2 = -256 * ey2; // one pixel to the right
-    const int32_t ay0 = 256 * ex0, ay1 = 256 * ex1, ay2 = 256 * ex2;    // one pixel down
+    // every difference below is < 2^15 and every product < 2^29: exact in 32 bits
+    const EdgeStart e = edge_start(t, bx0, by0);
+    const int32_t b1 = e.b1, b2 = e.b2;
+    const float rA = 1.0f / (float)(mul_narrow(e.ex2, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, e.ey2));
+    int32_t R0 = e.R0, R1 = e.R1, R2 = e.R2;
+    const int32_t ax0 = -256 * e.ey0, ax1 = -256 * e.ey1, ax2 = -256 * e.ey2; // one pixel to the right
+    const int32_t ay0 = 256 * e.ex0, ay1 = 256 * e.ex1, ay2 = 256 * e.ex2;    // one pixel down
     int32_t E0 = R0, E1 = R1, E2 = R2;
     int32_t i = bx0, j = by0;
-    const int32_t cnt = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+    const int32_t cnt = mul_narrow(bx1 - bx0 + 1, by1 - by0 + 1);
     for (int32_t k = 0; k < cnt; ++k) {
         if ((E0 | E1 | E2) >= 0) {
             const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
@@ -186,9 +177,9 @@ __device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, i
     w.is_narrow = narrow(t);
     const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
     // meaningful for narrow triangles only (every product below 2^28); others use the 64-bit loop
-    w.R0 = w.ex0 * (sy - t.y1) - w.ey0 * (sx - t.x1) - edge_bias(w.ex0, w.ey0);
-    w.R1 = w.ex1 * (sy - t.y2) - w.ey1 * (sx - t.x2) - w.b1;
-    w.R2 = w.ex2 * (sy - t.y0) - w.ey2 * (sx - t.x0) - w.b2;
+    w.R0 = mul_narrow(w.ex0, sy - t.y1) - mul_narrow(w.ey0, sx - t.x1) - edge_bias(w.ex0, w.ey0);
+    w.R1 = mul_narrow(w.ex1, sy - t.y2) - mul_narrow(w.ey1, sx - t.x2) - w.b1;
+    w.R2 = mul_narrow(w.ex2, sy - t.y0) - mul_narrow(w.ey2, sx - t.x0) - w.b2;
     w.rA = recip_area(t);
     w.qx0 = bx0; w.qy0 = by0;
     w.bw = (uint32_t)(bx1 - bx0 + 1);
@@ -214,11 +205,12 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
         const int32_t ax0 = -256 * SXE_RL(w.ey0), ax1 = -256 * SXE_RL(w.ey1), ax2 = -256 * SXE_RL(w.ey2);
         const int32_t ay0 = 256 * SXE_RL(w.ex0), ay1 = 256 * SXE_RL(w.ex1), ay2 = 256 * SXE_RL(w.ex2);
         for (uint32_t idx = first; idx < cnt; idx += stride) {
-            const uint32_t row = (idx * magic) >> 16;
-            const int32_t di = (int32_t)(idx - row * bw), dj = (int32_t)row;
-            const int32_t E0 = R0 + ax0 * di + ay0 * dj;
-            const int32_t E1 = R1 + ax1 * di + ay1 * dj;
-            const int32_t E2 = R2 + ax2 * di + ay2 * dj;
+            const uint32_t row = __umul24(idx, magic) >> 16;
+            const int32_t di = (int32_t)(idx - __umul24(row, bw)), dj = (int32_t)row;
+            // steps are below 2^22 and pixel offsets below 2^6: 24-bit multiplies are exact
+            const int32_t E0 = R0 + mul_narrow(ax0, di) + mul_narrow(ay0, dj);
+            const int32_t E1 = R1 + mul_narrow(ax1, di) + mul_narrow(ay1, dj);
+            const int32_t E2 = R2 + mul_narrow(ax2, di) + mul_narrow(ay2, dj);
             if ((E0 | E1 | E2) >= 0) {
                 const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
                 const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
@@ -231,8 +223,8 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
         const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
                         b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
         for (uint32_t idx = first; idx < cnt; idx += stride) {
-            const uint32_t row = (idx * magic) >> 16;
-            const int32_t i = qx0 + (int32_t)(idx - row * bw), j = qy0 + (int32_t)row;
+            const uint32_t row = __umul24(idx, magic) >> 16;
+            const int32_t i = qx0 + (int32_t)(idx - __umul24(row, bw)), j = qy0 + (int32_t)row;
             const long long sx = 256 * i + 128, sy = 256 * j + 128;
             const long long E0 = ex0 * (sy - y1) - ey0 * (sx - x1);
             const long long E1 = ex1 * (sy - y2) - ey1 * (sx - x2);
@@ -259,7 +251,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     if (a.counters->overflow) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[blockIdx.x]);
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
@@ -376,8 +368,6 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target.
     // A thread owns kTilePixels / kRasterThreads pixels and handles them kResolveBatch at a time,
     // stage by stage, so that the dependent loads of one stage are in flight together. ----
-    const float clr_r = s_dec[a.clear_code & 255], clr_g = s_dec[(a.clear_code >> 8) & 255];
-    const float clr_b = s_dec[(a.clear_code >> 16) & 255], clr_a = c_unorm8[(a.clear_code >> 24) & 255];
     const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
     // Uncovered pixels only need the clear values; covered ones are gathered into a dense list
     // first so that the shading loop runs with full waves.
@@ -459,12 +449,22 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
             if (cov[b]) {
                 const Tri t = unpack_tri(r[b], a.wide, slot[b]);
                 prim[b] = h[b].prim;
-                const float rA = recip_area(t);
-                const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
-                const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
-                const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
-                l1[b] = (float)E1 * rA;
-                l2[b] = (float)E2 * rA;
+                if (narrow(t)) { // same integers as below, from full-rate 24-bit multiplies
+                    const int32_t sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
+                    const int32_t area2 = mul_narrow(t.x1 - t.x0, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, t.y1 - t.y0);
+                    const int32_t E1 = mul_narrow(t.x0 - t.x2, sy - t.y2) - mul_narrow(t.y0 - t.y2, sx - t.x2);
+                    const int32_t E2 = mul_narrow(t.x1 - t.x0, sy - t.y0) - mul_narrow(t.y1 - t.y0, sx - t.x0);
+                    const float rA = 1.0f / (float)area2;
+                    l1[b] = (float)E1 * rA;
+                    l2[b] = (float)E2 * rA;
+                } else {
+                    const float rA = recip_area(t);
+                    const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
+                    const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
+                    const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
+                    l1[b] = (float)E1 * rA;
+                    l2[b] = (float)E2 * rA;
+                }
                 const float iw = (h[b].iw0 + l1[b] * h[b].diw1) + l2[b] * h[b].diw2;
                 riw[b] = 1.0f / iw;
                 if (a.shading != SXE_SHADE_VERTEX_COLOR) {
@@ -503,13 +503,14 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                         src[2] = (((c.bw0 + l1[b] * c.dbw1) + l2[b] * c.dbw2) * riw[b]) * src[2];
                     }
                 }
-                // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target
-                const float sa = src[3], ia = 1.0f - sa;
-                const uint32_t cr = srgb_encode_lds(s_thr, src[0] * sa + clr_r * ia);
-                const uint32_t cg = srgb_encode_lds(s_thr, src[1] * sa + clr_g * ia);
-                const uint32_t cb = srgb_encode_lds(s_thr, src[2] * sa + clr_b * ia);
-                const uint32_t ca = unorm8_encode(sa + clr_a * ia);
-                code[b] = cr | (cg << 8) | (cb << 16) | (ca << 24);
+                // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target:
+                // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 in every
+                // shading mode (textures must be opaque, vertex colours have no alpha), and then
+                // the blend returns Cs and 1 bit for bit, so it is not evaluated.
+                const uint32_t cr = srgb_encode_lds(s_thr, src[0]);
+                const uint32_t cg = srgb_encode_lds(s_thr, src[1]);
+                const uint32_t cb = srgb_encode_lds(s_thr, src[2]);
+                code[b] = cr | (cg << 8) | (cb << 16) | 0xFF000000u;
             }
 #pragma unroll
         for (int b = 0; b < kResolveBatch; ++b)

@@ -26,6 +26,10 @@ for lo, hi in [(0, 1), (1, 100), (100, 400), (400, 1000), (1000, 2000), (2000, 9
 edges = np.linspace(0, en.max(), 11)
 print("running workgroups at deciles of the span:", [int(((st <= t) & (en > t)).sum()) for t in edges[:-1] + 0.5 * (edges[1] - edges[0])])
 print("last 10 finishing tiles (entries, start, end):", sorted(zip(en.round(1), st.round(1), tc))[-10:])
+for title, sel in (("last finishing", np.argsort(en)[-8:]), ("longest", np.argsort(du)[-8:])):
+    print(title)
+    for q in sel:
+        print("   tile %5d entries %5d start %.1f dur %.1f: " % (q, tc[q], st[q], du[q]) + ", ".join("%s %.2f" % (n, (tt[q, b] - tt[q, a]) / 100.0) for n, (a, b) in zip(names, idx)))
 A = np.vstack([np.ones_like(tc), tc]).T.astype(float)
 coef = np.linalg.lstsq(A, du, rcond=None)[0]
 print("fit: dur = %.2f us + %.4f us * entries" % tuple(coef))
