@@ -140,23 +140,24 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    acc = {}
+    drawer.reset_timing_totals()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # frames are enqueued back to back (the library keeps up to three in flight on its
+        # stream); nothing waits on the host until the closing fence
         step(args.warmup + i)
-        # per-kernel device times come from HIP events the library records on its own stream
-        drawer.sync()
-        for k, v in drawer.timings().items():
-            acc[k] = acc.get(k, 0.0) + v
     fence()
     elapsed = time.perf_counter() - t0
+    # per-kernel device times: HIP events the library records on its own stream around every
+    # kernel of every timed frame
+    acc, timed_frames = drawer.timing_totals()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     stats = drawer.stats()
-    kern = {k: v / max(args.steps, 1) for k, v in acc.items()}
+    kern = {k: v / max(timed_frames, 1) for k, v in acc.items()}
     frames_per_step = 1 if (sortfirst or world == 1) else world
     total_frames = frames_per_step * args.steps
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)

@@ -173,6 +173,11 @@ int sxe_read_transforms(sxe_ctx *ctx, sxe_transform *transforms, size_t size_byt
 /* Device address of an image's RGBA8 rows (for a zero-copy RCCL tile gather). */
 int sxe_color_device_ptr(sxe_ctx *ctx, uint32_t image_index, void **ptr);
 int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
+/* Sums of the per-kernel times over every frame whose result has been taken since the last
+ * reset, and the number of those frames: lets a caller keep several frames in flight and still
+ * average kernel times (no counterpart in the reference, which has no timers). */
+int sxe_get_timing_totals(sxe_ctx *ctx, sxe_timings *sums, uint64_t *frames);
+int sxe_reset_timing_totals(sxe_ctx *ctx);
 /* Diagnostics: bin occupancy of the last frame, one count per rendered tile in row-major tile
  * order (load-balance analysis; no counterpart in the reference). */
 int sxe_read_tile_counts(sxe_ctx *ctx, uint32_t *counts, size_t size_bytes);

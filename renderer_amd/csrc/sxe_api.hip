@@ -57,6 +57,24 @@ struct Image {
 
 enum { EV_BEGIN = 0, EV_OBJECT, EV_SETUP, EV_SCAN, EV_BIN, EV_RASTER, EV_N };
 
+// Frames are enqueued without waiting for the one before (the reference keeps one frame per
+// swapchain image in flight the same way, src/renderer/drawer.rs:416-424).  What has to outlive a
+// frame until the host has looked at its result is kept per slot: the per-object matrices the
+// frame was drawn with (a redraw after growing a work buffer reuses them, whatever the transforms
+// have become since), the counters it reported and its timing events.
+constexpr int kFrameSlots = 3;
+struct FrameSlot {
+    DevBuf<float> pvm;
+    DevBuf<uint8_t> visible;
+    FrameCounters *h_counters = nullptr; // pinned
+    FrameCounters *d_counters = nullptr; // the same block as the device addresses it
+    hipEvent_t ev[EV_N] = {};
+    hipEvent_t ev_tr[2] = {};
+    hipEvent_t done = nullptr;
+    bool pending = false, transform_timed = false;
+    uint32_t image = 0;
+};
+
 } // namespace
 
 struct sxe_ctx {
@@ -76,7 +94,7 @@ struct sxe_ctx {
     DevBuf<InstDev> insts;
     DevBuf<BlockDesc> blocks;
     DevBuf<VBlockDesc> vblocks;
-    DevBuf<float> models, pvm;
+    DevBuf<float> models;
     DevBuf<sxe_transform> transforms;
     bool have_transforms = false;
     DevBuf<uint8_t> texels;
@@ -85,7 +103,6 @@ struct sxe_ctx {
 
     // per-frame work buffers
     DevBuf<uint32_t> blk_count, tile_counters /* count | fill front | fill back | launch order */, tile_off, bins, object_mesh, bin_keys;
-    DevBuf<uint8_t> visible;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
     DevBuf<ClipItem> clip_list;
@@ -94,16 +111,14 @@ struct sxe_ctx {
     DevBuf<FrameCounters> counters;
     DevBuf<float4> clip;
     DevBuf<unsigned long long> tile_times;
-    FrameCounters *h_counters = nullptr; // pinned
     size_t fan_capacity = 0, bin_capacity = 0; // records past the per-workgroup segments; bin entries
 
     std::vector<Image> images;
-    int last_image = -1;
-    bool frame_pending = false;
-    bool transform_timed = false;
-    hipEvent_t ev[EV_N] = {};
-    hipEvent_t ev_tr[2] = {};
+    FrameSlot slots[kFrameSlots];
+    uint64_t frames_enqueued = 0, frames_retired = 0; // frame f lives in slot f % kFrameSlots
     sxe_timings timings = {};
+    sxe_timings timing_totals = {};
+    uint64_t timed_frames = 0;
     sxe_frame_stats stats = {};
     uint32_t redraws = 0;
 };
@@ -190,9 +205,11 @@ hipError_t reserve_records(sxe_ctx *c)
 int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<HostObject> &ho)
 {
     SXE_HIP(c, hipSetDevice(c->cfg.device));
-    // finish whatever still reads the old scene
-    SXE_HIP(c, hipStreamSynchronize(c->stream));
-    c->frame_pending = false;
+    // finish (and settle) whatever still reads the old scene
+    {
+        const int rc = sxe_sync(c);
+        if (rc) return rc;
+    }
 
     const bool need_tex = c->cfg.shading != SXE_SHADE_VERTEX_COLOR;
     std::vector<MeshDev> meshes(hm.size());
@@ -319,8 +336,10 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     std::vector<uint32_t> object_mesh(ho.size());
     for (size_t o = 0; o < ho.size(); ++o) object_mesh[o] = ho[o].mesh;
     SXE_HIP(c, up(c->object_mesh, object_mesh));
-    SXE_HIP(c, c->visible.reserve(std::max<size_t>(ho.size(), 1)));
-    SXE_HIP(c, c->pvm.reserve(std::max<size_t>(models.size(), 16)));
+    for (FrameSlot &fs : c->slots) {
+        SXE_HIP(c, fs.visible.reserve(std::max<size_t>(ho.size(), 1)));
+        SXE_HIP(c, fs.pvm.reserve(std::max<size_t>(models.size(), 16)));
+    }
     SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1)));
 
     c->n_meshes = (uint32_t)hm.size();
@@ -345,33 +364,41 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     return SXE_OK;
 }
 
-ObjectArgs object_args(sxe_ctx *c)
+ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
 {
     ObjectArgs oa;
     oa.models = c->models.p;
     oa.pv = c->pv;
-    oa.pvm = c->pvm.p;
+    oa.pvm = fs.pvm.p;
     oa.meshes = c->meshes.p;
     oa.object_mesh = c->object_mesh.p;
-    oa.visible = c->visible.p;
+    oa.visible = fs.visible.p;
     oa.n = c->n_objects;
+    oa.objects = 1;
+    oa.zero = c->tile_counters.p;
+    oa.n_zero = 0;
+    oa.counters = c->counters.p;
     oa.g = c->g;
     return oa;
 }
 
-int enqueue_frame(sxe_ctx *c, uint32_t image_index)
+// Enqueues the frame of slot `fs`.  A redraw (fresh == false) keeps the slot's per-object matrices.
+int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
 {
-    Image &img = c->images[image_index];
+    Image &img = c->images[fs.image];
     const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
     hipStream_t s = c->stream;
     const uint32_t nt = c->g.n_tiles;
 
     const size_t ntc = std::max<uint32_t>(nt, 1);
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_BEGIN], s));
-    SXE_HIP(c, launch_object(object_args(c), s));
-    SXE_HIP(c, hipMemsetAsync(c->tile_counters.p, 0, 3 * ntc * sizeof(uint32_t), s));
-    SXE_HIP(c, hipMemsetAsync(c->counters.p, 0, sizeof(FrameCounters), s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_OBJECT], s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BEGIN], s));
+    {
+        ObjectArgs oa = object_args(c, fs);
+        oa.objects = fresh ? 1u : 0u;
+        oa.n_zero = (uint32_t)(3 * ntc); // count | fill front | fill back of every tile
+        SXE_HIP(c, launch_object(oa, s));
+    }
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_OBJECT], s));
 
     SetupArgs sa;
     sa.vertices = c->vertices.p;
@@ -379,8 +406,8 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sa.meshes = c->meshes.p;
     sa.insts = c->insts.p;
     sa.blocks = c->blocks.p;
-    sa.pvm = c->pvm.p;
-    sa.visible = c->visible.p;
+    sa.pvm = fs.pvm.p;
+    sa.visible = fs.visible.p;
     sa.n_blocks = c->n_blocks;
     sa.shading = c->cfg.shading;
     sa.debug = c->cfg.flags & kDebugMask;
@@ -397,7 +424,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sa.counters = c->counters.p;
     SXE_HIP(c, launch_setup(sa, s));
     SXE_HIP(c, launch_clip(sa, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_SETUP], s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SETUP], s));
 
     ScanArgs sc;
     sc.blk_count = c->blk_count.p;
@@ -409,7 +436,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
     sc.counters = c->counters.p;
     SXE_HIP(c, launch_scan(sc, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_SCAN], s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SCAN], s));
 
     BinArgs ba;
     ba.g = c->g;
@@ -426,7 +453,7 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ba.bins = c->bins.p;
     ba.counters = c->counters.p;
     SXE_HIP(c, launch_bin(ba, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_BIN], s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BIN], s));
 
     RasterArgs ra;
     ra.g = c->g;
@@ -451,13 +478,99 @@ int enqueue_frame(sxe_ctx *c, uint32_t image_index)
     ra.shading = c->cfg.shading;
     ra.tile_times = (c->cfg.flags & kDebugTileTimes) ? c->tile_times.p : nullptr;
     ra.debug = c->cfg.flags & kDebugMask;
+    // the tile kernel writes the counters into the slot's pinned block itself, unless it does not
+    // run or still changes them (development census)
+    const bool direct = nt > 0 && fs.d_counters && !(c->cfg.flags & kDebugSkipAtomic);
+    ra.host_counters = direct ? fs.d_counters : nullptr;
     SXE_HIP(c, launch_raster_shade(ra, s));
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev[EV_RASTER], s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_RASTER], s));
 
-    SXE_HIP(c, hipMemcpyAsync(c->h_counters, c->counters.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+    if (!direct) SXE_HIP(c, hipMemcpyAsync(fs.h_counters, c->counters.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+    SXE_HIP(c, hipEventRecord(fs.done, s));
     img.drawn = true;
-    c->last_image = (int)image_index;
-    c->frame_pending = true;
+    fs.pending = true;
+    return SXE_OK;
+}
+
+// Grows the work buffers to what the frame in `fs` asked for.  Nothing may be in flight.
+int grow_for(sxe_ctx *c, const FrameSlot &fs)
+{
+    const FrameCounters &k = *fs.h_counters;
+    // a full clip list hides how many fans its overflow would have produced: at most 7 each
+    const size_t fans = std::max<size_t>(k.fan_records, k.clip_count > c->fan_capacity ? (size_t)k.clip_count * kMaxFan : 0);
+    const size_t need_fan = fans + fans / 4 + 1024;
+    const size_t need_bin = (size_t)k.total_pairs + (size_t)k.total_pairs / 4 + 1024;
+    if (need_fan > c->fan_capacity) {
+        c->fan_capacity = need_fan;
+        SXE_HIP(c, reserve_records(c));
+    }
+    if (need_bin > c->bin_capacity) {
+        SXE_HIP(c, c->bins.reserve(need_bin));
+        c->bin_capacity = need_bin;
+    }
+    return SXE_OK;
+}
+
+// Takes the result of the oldest frame in flight: waits for it, and if one of its work buffers
+// was too small, grows the buffers and renders it again -- and after it every younger frame in
+// flight, in order, because they may share its image or have overflowed as well.
+int retire_oldest(sxe_ctx *c)
+{
+    FrameSlot &fs = c->slots[c->frames_retired % kFrameSlots];
+    SXE_HIP(c, hipEventSynchronize(fs.done));
+    if (fs.h_counters->overflow) {
+        SXE_HIP(c, hipStreamSynchronize(c->stream));
+        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
+            FrameSlot &r = c->slots[f % kFrameSlots];
+            // the oldest frame overflowed; the younger ones are drawn again after it in any case
+            for (int attempt = 0; attempt < 4 && (r.h_counters->overflow || (attempt == 0 && f > c->frames_retired)); ++attempt) {
+                int rc = grow_for(c, r);
+                if (rc) return rc;
+                c->redraws++;
+                rc = enqueue_frame(c, r, false);
+                if (rc) return rc;
+                SXE_HIP(c, hipStreamSynchronize(c->stream));
+            }
+            if (r.h_counters->overflow) {
+                // give up on everything in flight rather than report a half-drawn frame as good
+                for (FrameSlot &x : c->slots) x.pending = false;
+                c->frames_retired = c->frames_enqueued;
+                return fail(c, SXE_E_CAPACITY, "frame still overflows its work buffers after regrowth");
+            }
+        }
+    }
+    fs.pending = false;
+    c->frames_retired++;
+    const FrameCounters &k = *fs.h_counters;
+    c->stats.prims = c->n_prims;
+    c->stats.records = k.total_records;
+    c->stats.bin_entries = k.total_pairs;
+    c->stats.tiles = c->g.n_tiles;
+    c->stats.instance_vertices = c->n_inst_vertices;
+    c->stats.objects = c->n_objects;
+    c->stats.tile_size = kTile;
+    c->stats.redraws = c->redraws;
+    if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
+        fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", k.pad[0], k.pad[1],
+                k.pad[2], k.clip_count, k.fan_records);
+    if (c->cfg.flags & SXE_FLAG_TIMING) {
+        float ms[EV_N] = {};
+        for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], fs.ev[i - 1], fs.ev[i]));
+        sxe_timings &t = c->timings;
+        t.object_ms = ms[EV_OBJECT];
+        t.setup_ms = ms[EV_SETUP];
+        t.scan_ms = ms[EV_SCAN];
+        t.bin_ms = ms[EV_BIN];
+        t.raster_shade_ms = ms[EV_RASTER];
+        SXE_HIP(c, hipEventElapsedTime(&t.frame_ms, fs.ev[EV_BEGIN], fs.ev[EV_RASTER]));
+        t.transform_ms = 0.0f;
+        if (fs.transform_timed) SXE_HIP(c, hipEventElapsedTime(&t.transform_ms, fs.ev_tr[0], fs.ev_tr[1]));
+        fs.transform_timed = false;
+        sxe_timings &s = c->timing_totals;
+        s.transform_ms += t.transform_ms; s.object_ms += t.object_ms; s.setup_ms += t.setup_ms; s.scan_ms += t.scan_ms;
+        s.bin_ms += t.bin_ms; s.raster_shade_ms += t.raster_shade_ms; s.frame_ms += t.frame_ms;
+        c->timed_frames++;
+    }
     return SXE_OK;
 }
 
@@ -555,13 +668,20 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         return SXE_E_DEVICE;
     };
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (int i = 0; i < EV_N; ++i)
-        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return bail("hipEventCreate", e);
-    for (int i = 0; i < 2; ++i)
-        if ((e = hipEventCreate(&c->ev_tr[i])) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->h_counters), sizeof(FrameCounters), hipHostMallocDefault)) != hipSuccess)
-        return bail("hipHostMalloc", e);
-    memset(c->h_counters, 0, sizeof(FrameCounters));
+    for (FrameSlot &fs : c->slots) {
+        for (int i = 0; i < EV_N; ++i)
+            if ((e = hipEventCreate(&fs.ev[i])) != hipSuccess) return bail("hipEventCreate", e);
+        for (int i = 0; i < 2; ++i)
+            if ((e = hipEventCreate(&fs.ev_tr[i])) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&fs.done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&fs.h_counters), sizeof(FrameCounters), hipHostMallocDefault)) != hipSuccess)
+            return bail("hipHostMalloc", e);
+        memset(fs.h_counters, 0, sizeof(FrameCounters));
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&fs.d_counters), fs.h_counters, 0) != hipSuccess) {
+            fs.d_counters = nullptr; // not mapped: the counters are copied instead
+            (void)hipGetLastError();
+        }
+    }
     const size_t px = (size_t)k.width * k.height;
     c->images.resize(k.n_images);
     for (auto &img : c->images) {
@@ -592,14 +712,18 @@ void sxe_destroy(sxe_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
-    c->models.release(); c->pvm.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->visible.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release(); c->bin_keys.release();
+    c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release(); c->bin_keys.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    for (int i = 0; i < EV_N; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 2; ++i) if (c->ev_tr[i]) (void)hipEventDestroy(c->ev_tr[i]);
+    for (FrameSlot &fs : c->slots) {
+        fs.pvm.release(); fs.visible.release();
+        if (fs.h_counters) (void)hipHostFree(fs.h_counters);
+        for (int i = 0; i < EV_N; ++i) if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
+        for (int i = 0; i < 2; ++i) if (fs.ev_tr[i]) (void)hipEventDestroy(fs.ev_tr[i]);
+        if (fs.done) (void)hipEventDestroy(fs.done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -630,7 +754,8 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
         total += px;
         if (total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
     }
-    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    rc = sxe_sync(c); // frames in flight still sample the old table
+    if (rc) return rc;
     SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16)));
     SXE_HIP(c, c->textab.reserve(std::max<size_t>(n, 1)));
     for (uint32_t t = 0; t < n; ++t)
@@ -706,11 +831,17 @@ int sxe_rotation_system(sxe_ctx *c, uint64_t seed, uint32_t frame, float delta_m
     if (!c->have_scene) return fail(c, SXE_E_STATE, "rotation_system before update_drawables");
     if (!c->have_transforms) return fail(c, SXE_E_STATE, "model matrices were set directly; no transforms to rotate");
     const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
-    if (timing) SXE_HIP(c, hipEventRecord(c->ev_tr[0], c->stream));
+    // the update belongs to the frame drawn next: its events live in that frame's slot
+    if (c->frames_enqueued - c->frames_retired >= (uint64_t)kFrameSlots) {
+        rc = retire_oldest(c);
+        if (rc) return rc;
+    }
+    FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev_tr[0], c->stream));
     SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, delta_ms, c->stream));
     if (timing) {
-        SXE_HIP(c, hipEventRecord(c->ev_tr[1], c->stream));
-        c->transform_timed = true;
+        SXE_HIP(c, hipEventRecord(fs.ev_tr[1], c->stream));
+        fs.transform_timed = true;
     }
     return SXE_OK;
 }
@@ -746,71 +877,45 @@ int sxe_draw(sxe_ctx *c, uint32_t image_index)
     if (!c->have_scene) return fail(c, SXE_E_STATE, "draw before update_drawables");
     if (!c->have_camera) return fail(c, SXE_E_STATE, "draw before update_camera");
     if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
-    if (c->frame_pending) {
-        // a previous frame may still need its work buffers grown: settle it first
-        rc = sxe_sync(c);
+    // at most kFrameSlots frames are in flight: take the oldest one's result when all slots are used
+    if (c->frames_enqueued - c->frames_retired >= (uint64_t)kFrameSlots) {
+        rc = retire_oldest(c);
         if (rc) return rc;
     }
-    return enqueue_frame(c, image_index);
+    FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+    fs.image = image_index;
+    rc = enqueue_frame(c, fs, true);
+    if (rc) return rc;
+    c->frames_enqueued++;
+    return SXE_OK;
 }
 
 int sxe_sync(sxe_ctx *c)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
-    SXE_HIP(c, hipStreamSynchronize(c->stream));
-    if (!c->frame_pending) return SXE_OK;
-    for (int attempt = 0; attempt < 4 && c->h_counters->overflow; ++attempt) {
-        // a work buffer was too small: grow to what the frame asked for and render it again
-        // a full clip list hides how many fans its overflow would have produced: at most 7 each
-        const size_t fans = std::max<size_t>(c->h_counters->fan_records,
-                                             c->h_counters->clip_count > c->fan_capacity ? (size_t)c->h_counters->clip_count * kMaxFan : 0);
-        const size_t need_fan = fans + fans / 4 + 1024;
-        const size_t need_bin = (size_t)c->h_counters->total_pairs + (size_t)c->h_counters->total_pairs / 4 + 1024;
-        if (need_fan > c->fan_capacity) {
-            c->fan_capacity = need_fan;
-            SXE_HIP(c, reserve_records(c));
-        }
-        if (need_bin > c->bin_capacity) {
-            SXE_HIP(c, c->bins.reserve(need_bin));
-            c->bin_capacity = need_bin;
-        }
-        c->redraws++;
-        rc = enqueue_frame(c, (uint32_t)c->last_image);
+    while (c->frames_retired < c->frames_enqueued) {
+        rc = retire_oldest(c);
         if (rc) return rc;
-        SXE_HIP(c, hipStreamSynchronize(c->stream));
     }
-    c->frame_pending = false;
-    if (c->h_counters->overflow) return fail(c, SXE_E_CAPACITY, "frame still overflows its work buffers after regrowth");
-    c->stats.prims = c->n_prims;
-    c->stats.records = c->h_counters->total_records;
-    c->stats.bin_entries = c->h_counters->total_pairs;
-    c->stats.tiles = c->g.n_tiles;
-    c->stats.instance_vertices = c->n_inst_vertices;
-    c->stats.objects = c->n_objects;
-    c->stats.tile_size = kTile;
-    c->stats.redraws = c->redraws;
-    if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
-        fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", c->h_counters->pad[0],
-                c->h_counters->pad[1], c->h_counters->pad[2], c->h_counters->clip_count, c->h_counters->fan_records);
-    if ((c->cfg.flags & kDebugTileTimes) && getenv("SXE_DEBUG_COUNTERS")) {
-        const uint32_t *p = c->h_counters->pad;
-        const double w = p[8] ? (double)p[8] : 1.0;
-        fprintf(stderr, "[sxe] k_setup: %u working waves; mean ticks (10 ns) per wave: load+vertex %.1f, triangle %.1f, rank %.1f, "
-                        "records %.1f, count+clip %.1f\n", p[8], p[3] / w, p[4] / w, p[5] / w, p[6] / w, p[7] / w);
-    }
-    if (c->cfg.flags & SXE_FLAG_TIMING) {
-        float ms[EV_N] = {};
-        for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i - 1], c->ev[i]));
-        c->timings.object_ms = ms[EV_OBJECT];
-        c->timings.setup_ms = ms[EV_SETUP];
-        c->timings.scan_ms = ms[EV_SCAN];
-        c->timings.bin_ms = ms[EV_BIN];
-        c->timings.raster_shade_ms = ms[EV_RASTER];
-        SXE_HIP(c, hipEventElapsedTime(&c->timings.frame_ms, c->ev[EV_BEGIN], c->ev[EV_RASTER]));
-        c->timings.transform_ms = 0.0f;
-        if (c->transform_timed) SXE_HIP(c, hipEventElapsedTime(&c->timings.transform_ms, c->ev_tr[0], c->ev_tr[1]));
-    }
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    return SXE_OK;
+}
+
+int sxe_get_timing_totals(sxe_ctx *c, sxe_timings *sums, uint64_t *frames)
+{
+    if (!c || !sums || !frames) return fail(c, SXE_E_INVALID, "null argument");
+    if (!(c->cfg.flags & SXE_FLAG_TIMING)) return fail(c, SXE_E_STATE, "context was created without SXE_FLAG_TIMING");
+    *sums = c->timing_totals;
+    *frames = c->timed_frames;
+    return SXE_OK;
+}
+
+int sxe_reset_timing_totals(sxe_ctx *c)
+{
+    if (!c) return fail(c, SXE_E_INVALID, "null context");
+    c->timing_totals = sxe_timings{};
+    c->timed_frames = 0;
     return SXE_OK;
 }
 
@@ -836,9 +941,12 @@ int sxe_read_clip_positions(sxe_ctx *c, float *clip, size_t size_bytes)
     if (!c->have_scene || !c->have_camera) return fail(c, SXE_E_STATE, "read_clip_positions needs a scene and a camera");
     const size_t need = (size_t)c->n_inst_vertices * 16;
     if (!clip || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    rc = sxe_sync(c); // the matrices go through a frame slot: none may be in use
+    if (rc) return rc;
     SXE_HIP(c, c->clip.reserve(std::max<size_t>(c->n_inst_vertices, 1)));
-    SXE_HIP(c, launch_object(object_args(c), c->stream));
-    SXE_HIP(c, launch_vertex(c->pos_x.p, c->pos_y.p, c->pos_z.p, c->meshes.p, c->vblocks.p, c->n_vblocks, c->pvm.p,
+    FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+    SXE_HIP(c, launch_object(object_args(c, fs), c->stream));
+    SXE_HIP(c, launch_vertex(c->pos_x.p, c->pos_y.p, c->pos_z.p, c->meshes.p, c->vblocks.p, c->n_vblocks, fs.pvm.p,
                              c->clip.p, c->stream));
     SXE_HIP(c, hipStreamSynchronize(c->stream));
     if (need) SXE_HIP(c, hipMemcpy(clip, c->clip.p, need, hipMemcpyDeviceToHost));

@@ -33,10 +33,13 @@ namespace sxe {
 // does too, so every one of its triangles would be rejected one by one anyway.  The same holds
 // for objects that project wholly above or below the scissor rows.  Skipping such objects changes
 // no pixel.
+// It is also the first kernel of a frame and clears the frame's counters on the way.
 __global__ void k_object(ObjectArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    for (uint32_t z = i; z < a.n_zero; z += gridDim.x * blockDim.x) a.zero[z] = 0u;
+    if (i < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t *>(a.counters)[i] = 0u;
+    if (i >= a.n || !a.objects) return;
     Mat4 M;
     const float4 *src = reinterpret_cast<const float4 *>(a.models + 16 * (size_t)i);
     for (int c = 0; c < 4; ++c) {
@@ -799,8 +802,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
 
 hipError_t launch_object(const ObjectArgs &a, hipStream_t s)
 {
-    if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_object, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_object, dim3(a.n / 256 + 1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

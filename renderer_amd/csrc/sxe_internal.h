@@ -131,6 +131,10 @@ struct ObjectArgs {
     const uint32_t *object_mesh; // mesh of every object (caller order)
     uint8_t *visible;            // 0: the whole object is outside the view volume or the scissor band
     uint32_t n;
+    uint32_t objects;            // 0: only clear the counters (a frame drawn again keeps its matrices)
+    uint32_t *zero;              // per-tile counters to clear
+    uint32_t n_zero;
+    FrameCounters *counters;     // cleared as well
     FrameGeom g;
 };
 
@@ -202,6 +206,7 @@ struct RasterArgs {
     const ShadeRec *shade;
     const ColorRec *color;
     const FrameCounters *counters;
+    FrameCounters *host_counters; // host-visible copy of the counters, written by the first workgroup (may be null)
     const uint8_t *texels;
     const TexDev *textures;
     uint32_t n_textures;

@@ -248,6 +248,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     __shared__ uint32_t s_wq[kWideQueue];
     __shared__ uint32_t s_nwq, s_ncov;
     __shared__ uint16_t s_cov[kTilePixels]; // tile-local indices of the covered pixels
+    // the frame's counters are final by now: report them to the host without a copy command
+    if (blockIdx.x == 0 && a.host_counters && threadIdx.x < sizeof(FrameCounters) / 4)
+        reinterpret_cast<uint32_t *>(a.host_counters)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.counters)[threadIdx.x];
     if (a.counters->overflow) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -171,6 +171,61 @@ def test_work_buffers_grow_on_demand(orc):
     assert_frames_equal(got, ref, what="regrown buffers")
 
 
+def test_frames_in_flight(orc):
+    """Frames enqueued back to back without a host wait: every image must hold exactly its frame,
+    also when the first frames overflow their work buffers and are drawn again after the fact
+    (with the matrices they were submitted with, although the transforms have moved on)."""
+    s = scenes.config_scene(3, scale=0.03)
+    w, h = s.size
+    view, proj = orc.camera(s.camera, w, h)
+    for n_images in (1, 3):
+        t = s.transforms.copy()
+        refs = []
+        with api.HipDrawer(w, h, n_images=n_images, coverage=True, timing=True) as d:
+            d.update_scene(s)
+            d.update_camera(s.camera)
+            for f in range(5):
+                d.rotation_system(3, f, 400.0)  # large steps: consecutive frames differ visibly
+                orc.rotation_system(t, 3, f, 400.0)
+                d.draw(f % n_images)
+                refs.append(orc.render(s, orc.to_model(t), view, proj, w, h))
+            d.sync()
+            sums, frames = d.timing_totals()
+            assert frames == 5 and sums["raster_shade_ms"] > 0.0
+            for img in range(n_images):
+                last = max(f for f in range(5) if f % n_images == img)
+                got = {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)}
+                assert_frames_equal(got, refs[last], what="image %d of %d holds frame %d" % (img, n_images, last))
+        assert not np.array_equal(refs[3]["color"], refs[4]["color"])
+
+
+def test_frames_in_flight_with_late_overflow(orc):
+    """The first frames of a scene whose bins outgrow the first guess are in flight together."""
+    from tests.util import soup_scene
+    rng = np.random.default_rng(9)
+    n = 3000
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[..., :2] = rng.uniform(-1, 1, (n, 3, 2))
+    tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
+    s = soup_scene(tris, width=512, height=512)
+    m0 = np.tile(IDENT, (1, 1)).astype(np.float32)
+    m1 = m0.copy()
+    m1[0, 12] = 0.25  # second frame: the whole soup moved to the right
+    refs = [orc.render(s, m, IDENT, IDENT, 512, 512) for m in (m0, m1)]
+    with api.HipDrawer(512, 512, n_images=2, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera_matrices(IDENT, IDENT)
+        d.update_uniforms(m0)
+        d.draw(0)
+        d.update_uniforms(m1)
+        d.draw(1)
+        d.sync()
+        assert d.stats()["redraws"] >= 2
+        for img in (0, 1):
+            got = {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)}
+            assert_frames_equal(got, refs[img], what="late overflow, image %d" % img)
+
+
 def test_error_behaviour(orc):
     s = scenes.cube_scene(64, 64)
     with api.HipDrawer(64, 64) as d:
