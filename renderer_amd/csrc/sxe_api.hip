@@ -452,6 +452,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.fill_back = c->tile_counters.p + 2 * ntc;
     ba.bins = c->bins.p;
     ba.counters = c->counters.p;
+    // the binning switches leave the bins unusable: only honoured when the tile kernel skips them
+    ba.debug = (c->cfg.flags & kDebugSkipRaster) ? (c->cfg.flags & kDebugMask) : 0u;
     SXE_HIP(c, launch_bin(ba, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BIN], s));
 

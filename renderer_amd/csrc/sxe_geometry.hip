@@ -400,7 +400,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         }
         __syncthreads();
     }
-    if (a.debug & kDebugSkipRaster) { // development: stop after the vertex phase
+    if ((a.debug & kDebugSkipRaster) && (a.debug & kDebugSkipResolve)) { // development: stop after the vertex phase
         if (tid == 0) a.blk_count[block] = 0;
         return;
     }
@@ -494,7 +494,12 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // (the rank barrier above came after the last read of the vertex arrays, which `stage` overlays)
     if (state != CULLED) {
         const bool big = (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kSmallBox;
-        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 2u + (big ? 1u : 0u) : kBinKeyFromRecord);
+        const uint32_t cols = (uint32_t)(st.px1 / kTile - tx0), rows = (uint32_t)(st.py1 / kTile - ty0); // minus one
+        const uint32_t block_key = (cols < 16u && rows < 16u)
+                                       ? kBinKeyBlock | (big ? 1u << 29 : 0u) | (rows << 25) | (cols << 21) |
+                                             ((uint32_t)(ty0 - (int32_t)a.g.tile_row0) << 8) | (uint32_t)tx0
+                                       : kBinKeyFromRecord;
+        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 2u + (big ? 1u : 0u) : block_key);
         sh.stage[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
         sh.stage[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), r.order);
     }
@@ -708,35 +713,81 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // whose pixel box inside the tile holds at most kSmallBox pixels are stored from the front of the
 // tile's range, the others from its back, so that the raster kernel meets boxes of similar size
 // next to each other.  The order of entries inside a bin is irrelevant to the image.
-// One round of a wave: lane l files record `rec` under `key` (a kBinKey* value or 2 * tile + class).
-__device__ inline void bin_round(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, int lane)
+// A wave files 64 records in two steps so that the memory round trips of several such rounds
+// overlap: `bin_reserve` groups the lanes by key and lets every group leader reserve the group's
+// run of bin entries (one atomic per group), `bin_store` writes the slot numbers once the
+// reservations have come back.  A key is a kBinKey* value or 2 * tile + class.
+struct BinTicket {
+    uint32_t base;   // reserved start of the group, valid in the group's leader lane
+    uint32_t off, count; // the tile's bin range
+    int leader;
+    uint32_t rank;
+};
+
+__device__ inline BinTicket bin_reserve(const BinArgs &a, bool valid, uint32_t key, int lane)
 {
-    const bool single = valid && key < kBinKeyNone;
+    const bool single = valid && key < kBinKeyBlock;
     const uint32_t tile = key >> 1;
+    BinTicket t;
+    t.base = 0; t.off = 0; t.count = 0; t.leader = lane; t.rank = 0;
     // group the lanes of the wave by (tile, class) without touching memory ...
     unsigned long long pending = __ballot(single);
-    int my_leader = lane;
-    uint32_t my_rank = 0, my_count = 0;
+    uint32_t my_count = 0;
     while (pending) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
         const uint32_t lk = __builtin_amdgcn_readlane(key, leader);
         const bool mine = single && key == lk;
         const unsigned long long same = __ballot(mine);
         if (mine) {
-            my_leader = leader;
-            my_rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            t.leader = leader;
+            t.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             my_count = (uint32_t)__popcll(same);
         }
         pending &= ~same;
     }
     // ... then every group leader reserves its run of bin entries in one round of atomics
-    uint32_t base = 0;
-    if (single && lane == my_leader) base = atomicAdd((key & 1u) ? &a.fill_back[tile] : &a.fill_front[tile], my_count);
-    base = __shfl(base, my_leader);
     if (single) {
-        const uint32_t p = base + my_rank;
-        const uint32_t off = a.tile_off[tile];
-        a.bins[(key & 1u) ? off + a.tile_count[tile] - 1u - p : off + p] = rec;
+        t.off = a.tile_off[tile];
+        t.count = a.tile_count[tile];
+        if (lane == t.leader) t.base = atomicAdd((key & 1u) ? &a.fill_back[tile] : &a.fill_front[tile], my_count);
+    }
+    return t;
+}
+
+__device__ inline void bin_store(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, const BinTicket &t)
+{
+    const uint32_t base = __shfl(t.base, t.leader);
+    if (valid && key < kBinKeyBlock) {
+        const uint32_t p = base + t.rank;
+        a.bins[(key & 1u) ? t.off + t.count - 1u - p : t.off + p] = rec;
+    }
+    if (valid && (key & 0xC0000000u) == kBinKeyBlock) {
+        // a block of tiles: the reservations of its first four tiles travel together
+        const uint32_t cols = ((key >> 21) & 15u) + 1u, rows = ((key >> 25) & 15u) + 1u, n_t = cols * rows;
+        const uint32_t first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
+        const bool big = (key >> 29) & 1u;
+        uint32_t *fill = big ? a.fill_back : a.fill_front;
+        uint32_t pos[4], off[4], cnt[4];
+        uint32_t cx = 0, cy = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < n_t) {
+                const uint32_t tl = first + cy * a.g.tiles_x + cx;
+                off[j] = a.tile_off[tl];
+                cnt[j] = a.tile_count[tl];
+                pos[j] = atomicAdd(&fill[tl], 1u);
+                if (++cx == cols) { cx = 0; ++cy; }
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((uint32_t)j < n_t) a.bins[big ? off[j] + cnt[j] - 1u - pos[j] : off[j] + pos[j]] = rec;
+        for (uint32_t j = 4; j < n_t; ++j) {
+            const uint32_t tl = first + cy * a.g.tiles_x + cx;
+            const uint32_t o = a.tile_off[tl], n = a.tile_count[tl];
+            const uint32_t p = atomicAdd(&fill[tl], 1u);
+            a.bins[big ? o + n - 1u - p : o + p] = rec;
+            if (++cx == cols) { cx = 0; ++cy; }
+        }
     }
     if (valid && key == kBinKeyFromRecord) {
         const RastRec r = a.rast[rec];
@@ -782,17 +833,31 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
             const uint32_t i = 64u * k + (uint32_t)lane;
             keys[k] = i < cnt ? a.bin_keys[seg * kSetupThreads + i] : kBinKeyNone;
         }
-#pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k) {
-            if (64u * k >= cnt) break;
-            const uint32_t i = 64u * k + (uint32_t)lane;
-            bin_round(a, i < cnt, seg * kSetupThreads + i, keys[k], lane);
+        if (a.debug & kDebugSkipSmall) { // development: stop after the loads
+            if ((keys[0] ^ keys[1] ^ keys[2] ^ keys[3]) == 0x12345678u) a.bins[0] = 0;
+            return;
         }
+        BinTicket tickets[kSetupThreads / 64];
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k)
+            if (64u * k < cnt) tickets[k] = bin_reserve(a, 64u * k + (uint32_t)lane < cnt, keys[k], lane);
+        if (a.debug & kDebugSkipLarge) { // development: stop after the reservations
+            if ((tickets[0].base ^ tickets[0].off) == 0x12345678u) a.bins[0] = 0;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k)
+            if (64u * k < cnt) {
+                const uint32_t i = 64u * k + (uint32_t)lane;
+                bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], tickets[k]);
+            }
     } else {
         const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
         const uint32_t n_fan = a.counters->fan_records;
         if (first >= n_fan) return;
-        bin_round(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, lane);
+        const bool valid = first + lane < n_fan;
+        const BinTicket t = bin_reserve(a, valid, kBinKeyFromRecord, lane);
+        bin_store(a, valid, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, t);
     }
 }
 

@@ -164,7 +164,10 @@ struct SetupArgs {
 
 // Bin keys: 2 * tile + (1 if the pixel box holds more than kSmallBox pixels) for a triangle whose
 // box lies in one tile; the two values below otherwise.
-constexpr uint32_t kBinKeyFromRecord = 0xFFFFFFFFu; // several tiles: k_bin derives them from the record
+// A triangle whose box spans a block of at most 16 x 16 tiles: kBinKeyBlock | class << 29 |
+// (rows - 1) << 25 | (columns - 1) << 21 | first tile row (of the rendered rows) << 8 | first column.
+constexpr uint32_t kBinKeyBlock = 0x80000000u;
+constexpr uint32_t kBinKeyFromRecord = 0xFFFFFFFFu; // larger blocks and fans: k_bin derives the tiles from the record
 constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a clipped triangle
 
 struct ScanArgs {
@@ -192,6 +195,7 @@ struct BinArgs {
     uint32_t *fill_back;       // per tile: the others, filled downwards from the end of the bin
     uint32_t *bins;
     const FrameCounters *counters;
+    uint32_t debug;            // kDebug* switches (development only; need kDebugSkipRaster as well)
 };
 
 struct RasterArgs {

@@ -396,6 +396,24 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     __syncthreads();
     SXE_STAMP(5);
     const uint32_t n_cov = s_ncov;
+    // The records of a thread's next pixel are requested before its current pixel is shaded, so
+    // that their round trip overlaps the texel fetches of the current one.
+    ShadeRec h_next;
+    uint4 geo_next = make_uint4(0, 0, 0, 0); // x0, y0 and the packed corner offsets of the winning triangle
+    uint32_t slot_next = 0, pix_next = 0;
+    float depth_next = 1.0f;
+    h_next.iw0 = h_next.diw1 = h_next.diw2 = h_next.uw0 = h_next.duw1 = h_next.duw2 = h_next.vw0 = h_next.dvw1 = h_next.dvw2 = 0.0f;
+    h_next.prim = h_next.fan_base = h_next.tex_fan = 0;
+#define SXE_REQUEST(q)                                                                     \
+    do {                                                                                   \
+        pix_next = s_cov[(q)];                                                             \
+        const unsigned long long key_ = vis[pix_next];                                     \
+        slot_next = (uint32_t)key_;                                                        \
+        depth_next = __uint_as_float((uint32_t)(key_ >> 32));                              \
+        h_next = a.shade[slot_next];                                                       \
+        geo_next = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)slot_next];         \
+    } while (0)
+    if ((uint32_t)tid < n_cov) SXE_REQUEST(tid);
     for (uint32_t q0 = (uint32_t)tid; q0 < n_cov; q0 += kRasterThreads * kResolveBatch) {
         bool live[kResolveBatch], cov[kResolveBatch];
         uint32_t slot[kResolveBatch], prim[kResolveBatch], code[kResolveBatch];
@@ -403,25 +421,18 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
         int32_t px[kResolveBatch], py[kResolveBatch];
         ShadeRec h[kResolveBatch];
         RastRec r[kResolveBatch];
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b) {
-            const uint32_t q = q0 + (uint32_t)b * kRasterThreads;
-            live[b] = cov[b] = q < n_cov;
-            const uint32_t pix = cov[b] ? s_cov[q] : 0u;
-            px[b] = tpx + (int32_t)(pix & (kTile - 1));
-            py[b] = tpy + (int32_t)(pix / kTile);
-            const unsigned long long key = vis[pix];
-            slot[b] = (uint32_t)key;
-            depth[b] = __uint_as_float((uint32_t)(key >> 32));
-            prim[b] = 0xFFFFFFFFu;
-            code[b] = a.clear_code;
-        }
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b)
-            if (cov[b]) {
-                h[b] = a.shade[slot[b]];
-                r[b] = a.rast[slot[b]];
-            }
+        static_assert(kResolveBatch == 1, "the request-ahead scheme handles one pixel per thread and round");
+        live[0] = cov[0] = true;
+        px[0] = tpx + (int32_t)(pix_next & (kTile - 1));
+        py[0] = tpy + (int32_t)(pix_next / kTile);
+        slot[0] = slot_next;
+        depth[0] = depth_next;
+        prim[0] = 0xFFFFFFFFu;
+        code[0] = a.clear_code;
+        h[0] = h_next;
+        r[0].x0 = (int32_t)geo_next.x; r[0].y0 = (int32_t)geo_next.y; r[0].d1 = geo_next.z; r[0].d2 = geo_next.w;
+        r[0].z0 = r[0].dz1 = r[0].dz2 = 0.0f; r[0].order = slot_next; // the depth planes are not needed any more
+        if (q0 + kRasterThreads < n_cov) SXE_REQUEST(q0 + kRasterThreads);
 #pragma unroll
         for (int b = 0; b < kResolveBatch; ++b)
             if (cov[b] && (h[b].tex_fan >> 24)) {
@@ -524,6 +535,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                 if (COVERAGE) a.out_prim[p] = prim[b];
             }
     }
+#undef SXE_REQUEST
     SXE_STAMP(7);
 }
 
