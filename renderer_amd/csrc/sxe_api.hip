@@ -102,7 +102,8 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, tile_counters /* count | fill front | fill back | launch order */, tile_off, bins, object_mesh, bin_keys;
+    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos;
+    DevBuf<uint4> bin_pos4;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
     DevBuf<ClipItem> clip_list;
@@ -196,6 +197,8 @@ hipError_t reserve_records(sxe_ctx *c)
     if ((e = c->wide.reserve(n)) != hipSuccess) return e;
     if ((e = c->shade.reserve(n)) != hipSuccess) return e;
     if ((e = c->bin_keys.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
+    if ((e = c->bin_pos.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
+    if ((e = c->bin_pos4.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if (c->cfg.shading != SXE_SHADE_TEXTURE && (e = c->color.reserve(n)) != hipSuccess) return e;
     return c->clip_list.reserve(c->fan_capacity);
 }
@@ -395,7 +398,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     {
         ObjectArgs oa = object_args(c, fs);
         oa.objects = fresh ? 1u : 0u;
-        oa.n_zero = (uint32_t)(3 * ntc); // count | fill front | fill back of every tile
+        oa.n_zero = (uint32_t)(5 * ntc); // the TileCtr of every tile, then the late-fill counters
         SXE_HIP(c, launch_object(oa, s));
     }
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_OBJECT], s));
@@ -413,7 +416,9 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sa.debug = c->cfg.flags & kDebugMask;
     sa.g = c->g;
     sa.blk_count = c->blk_count.p;
-    sa.tile_count = c->tile_counters.p;
+    sa.tiles = reinterpret_cast<TileCtr *>(c->tile_counters.p);
+    sa.bin_pos = c->bin_pos.p;
+    sa.bin_pos4 = c->bin_pos4.p;
     sa.rast = c->rast.p;
     sa.wide = c->wide.p;
     sa.shade = c->shade.p;
@@ -429,9 +434,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ScanArgs sc;
     sc.blk_count = c->blk_count.p;
     sc.n_blocks = c->n_blocks;
-    sc.tile_count = sa.tile_count;
-    sc.tile_off = c->tile_off.p;
-    sc.tile_order = c->tile_counters.p + 3 * ntc;
+    sc.tiles = sa.tiles;
+    sc.tile_order = c->tile_counters.p + 5 * ntc;
     sc.n_tiles = nt;
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
     sc.counters = c->counters.p;
@@ -446,10 +450,10 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.rast = c->rast.p;
     ba.wide = c->wide.p;
     ba.bin_keys = c->bin_keys.p;
-    ba.tile_count = sa.tile_count;
-    ba.tile_off = c->tile_off.p;
-    ba.fill_front = c->tile_counters.p + ntc;
-    ba.fill_back = c->tile_counters.p + 2 * ntc;
+    ba.bin_pos = c->bin_pos.p;
+    ba.bin_pos4 = c->bin_pos4.p;
+    ba.tiles = sa.tiles;
+    ba.late_fill = c->tile_counters.p + 4 * ntc;
     ba.bins = c->bins.p;
     ba.counters = c->counters.p;
     // the binning switches leave the bins unusable: only honoured when the tile kernel skips them
@@ -459,9 +463,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
 
     RasterArgs ra;
     ra.g = c->g;
-    ra.tile_count = sa.tile_count;
-    ra.tile_off = c->tile_off.p;
-    ra.fill_front = ba.fill_front;
+    ra.tiles = sa.tiles;
     ra.tile_order = sc.tile_order;
     ra.bins = c->bins.p;
     ra.rast = c->rast.p;
@@ -697,8 +699,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(4 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
-    if ((e = c->tile_off.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile offsets)", e);
+    if ((e = c->tile_counters.reserve(6 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
@@ -715,7 +716,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->tile_off.release(); c->bin_keys.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->bin_pos.release(); c->bin_pos4.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
@@ -995,7 +996,11 @@ int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
     if (!counts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     rc = sxe_sync(c);
     if (rc) return rc;
-    if (need) SXE_HIP(c, hipMemcpy(counts, c->tile_counters.p, need, hipMemcpyDeviceToHost));
+    if (need) {
+        std::vector<TileCtr> ctr(c->g.n_tiles);
+        SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ctr.size(); ++i) counts[i] = bin_size(ctr[i]);
+    }
     return SXE_OK;
 }
 

@@ -347,7 +347,7 @@ __device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
     const int32_t tx0 = s.px0 / kTile, tx1 = s.px1 / kTile;
     const int32_t ty0 = s.py0 / kTile - (int32_t)a.g.tile_row0, ty1 = s.py1 / kTile - (int32_t)a.g.tile_row0;
     for (int32_t ty = ty0; ty <= ty1; ++ty)
-        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&a.tile_count[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx], 1u);
+        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&a.tiles[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx].multi, 1u);
 }
 
 // One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object
@@ -357,6 +357,7 @@ __device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
 struct SetupShared {
     uint32_t wave_tot[kSetupThreads / 64];
     uint32_t keys[kSetupThreads];
+    uint32_t pos[kSetupThreads];
     union {
         // first the projected vertices of the work item's triangles: position, (z/w, 1/w), (u/w, v/w), flags
         struct {
@@ -407,7 +408,6 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
 
     enum { CULLED = 0, FAST = 1, CLIP = 2 };
     int state = CULLED;
-    uint32_t vi0 = 0, vi1 = 0, vi2 = 0;
     ScreenTri st;
     st.px0 = st.px1 = st.py0 = st.py1 = 0;
     Attr3 uw = {0, 0, 0}, vw = {0, 0, 0};
@@ -415,9 +415,6 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     if (valid) {
         const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
         const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
-        vi0 = bd.vtx_base + i0;
-        vi1 = bd.vtx_base + i1;
-        vi2 = bd.vtx_base + i2;
         PVert v0, v1, v2;
         if (cached) {
             const uint32_t k0 = i0 - bd.vtx_lo, k1 = i1 - bd.vtx_lo, k2 = i2 - bd.vtx_lo;
@@ -430,7 +427,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
             uw = {t0.x, t1.x, t2.x};
             vw = {t0.y, t1.y, t2.y};
         } else {
-            const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
+            const sxe_vertex &w0 = a.vertices[bd.vtx_base + i0], &w1 = a.vertices[bd.vtx_base + i1], &w2 = a.vertices[bd.vtx_base + i2];
             v0 = project_vertex(transform_vertex(pvm, w0.pos[0], w0.pos[1], w0.pos[2]), a.g);
             v1 = project_vertex(transform_vertex(pvm, w1.pos[0], w1.pos[1], w1.pos[2]), a.g);
             v2 = project_vertex(transform_vertex(pvm, w2.pos[0], w2.pos[1], w2.pos[2]), a.g);
@@ -470,6 +467,53 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     const uint32_t slot0 = block * kSetupThreads, slot = slot0 + local;
     const uint32_t prim = bd.prim_base + t;
 
+    // Bin entries of triangles that lie in one tile are reserved here, one atomic per (tile, size
+    // class) group of the wave; the reply is needed only when the keys are staged further down.
+    const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
+    const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
+    const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
+    const bool big = (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kSmallBox;
+    // A triangle that touches up to four tiles reserves an entry at the back of each of those
+    // bins as well; larger ones are only counted and take their entries in k_bin.
+    const uint32_t cols_m1 = (uint32_t)(st.px1 / kTile - tx0), rows_m1 = (uint32_t)(st.py1 / kTile - ty0);
+    const uint32_t n_touched = (cols_m1 + 1u) * (rows_m1 + 1u);
+    const bool few = (state == FAST) && !single && n_touched <= 4u;
+    // Entry j of a lane goes to the counter 2 * tile + part (part 1: the back of the bin).  The
+    // lanes of the wave whose entry j names the same counter share one atomic: neighbouring
+    // triangles fall into the same tiles, and a reservation that many lanes make on one counter
+    // one after the other is slow to come back.
+    uint32_t raw4[4] = {0, 0, 0, 0};   // the group's reservation, valid in its leader lane
+    uint32_t who4[4] = {0, 0, 0, 0};   // leader lane | rank inside the group << 8
+    {
+        const uint32_t first = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+        uint32_t cx = 0, cy = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool has = (j == 0 && single) || (few && (uint32_t)j < n_touched);
+            const uint32_t counter = 2u * (first + cy * a.g.tiles_x + cx) + ((single && !big) ? 0u : 1u);
+            uint32_t count_j = 0;
+            who4[j] = (uint32_t)lane;
+            unsigned long long pending = __ballot(has);
+            while (pending) {
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+                const uint32_t lk = __builtin_amdgcn_readlane(counter, leader);
+                const bool mine = has && counter == lk;
+                const unsigned long long same = __ballot(mine);
+                if (mine) {
+                    who4[j] = (uint32_t)leader | ((uint32_t)__popcll(same & ((1ull << lane) - 1ull)) << 8);
+                    count_j = (uint32_t)__popcll(same);
+                }
+                pending &= ~same;
+            }
+            if (has && (uint32_t)lane == (who4[j] & 255u)) {
+                TileCtr &tc = a.tiles[counter >> 1];
+                raw4[j] = atomicAdd((counter & 1u) ? &tc.back : &tc.front, count_j);
+            }
+            if (++cx > cols_m1) { cx = 0; ++cy; }
+        }
+    }
+    if (state == FAST && !single && !few) count_box(a, st);
+
     // The records go to memory through LDS: a lane storing its own 32- and 48-byte records would
     // send the L2 one 16-byte request per lane and instruction; laid out in slot order first, the
     // workgroup stores them as whole cache lines.
@@ -481,20 +525,25 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     if (state == FAST) {
         Attr3 cr = {0, 0, 0}, cg = {0, 0, 0}, cb = {0, 0, 0};
         if (a.shading != SXE_SHADE_TEXTURE) {
-            const sxe_vertex &w0 = a.vertices[vi0], &w1 = a.vertices[vi1], &w2 = a.vertices[vi2];
+            // (the indices are read again rather than kept in registers all the way down here)
+            const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
+            const sxe_vertex &w0 = a.vertices[bd.vtx_base + ip[0]], &w1 = a.vertices[bd.vtx_base + ip[1]],
+                             &w2 = a.vertices[bd.vtx_base + ip[2]];
             cr = {w0.color[0], w1.color[0], w2.color[0]};
             cg = {w0.color[1], w1.color[1], w2.color[1]};
             cb = {w0.color[2], w1.color[2], w2.color[2]};
         }
         make_records(a, slot, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
     }
-    const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
-    const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
-    const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
+    uint32_t reserved4[4]; // position of this lane's entry j in its bin part
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reserved4[j] = (uint32_t)__shfl((int)raw4[j], (int)(who4[j] & 255u)) + (who4[j] >> 8);
+    const uint32_t bin_pos = reserved4[0];
+    if (few) a.bin_pos4[slot] = make_uint4(reserved4[0], reserved4[1], reserved4[2], reserved4[3]);
     // (the rank barrier above came after the last read of the vertex arrays, which `stage` overlays)
     if (state != CULLED) {
-        const bool big = (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kSmallBox;
-        const uint32_t cols = (uint32_t)(st.px1 / kTile - tx0), rows = (uint32_t)(st.py1 / kTile - ty0); // minus one
+        sh.pos[local] = bin_pos;
+        const uint32_t cols = cols_m1, rows = rows_m1;
         const uint32_t block_key = (cols < 16u && rows < 16u)
                                        ? kBinKeyBlock | (big ? 1u << 29 : 0u) | (rows << 25) | (cols << 21) |
                                              ((uint32_t)(ty0 - (int32_t)a.g.tile_row0) << 8) | (uint32_t)tx0
@@ -504,7 +553,10 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         sh.stage[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), r.order);
     }
     __syncthreads();
-    if ((uint32_t)tid < total) a.bin_keys[slot0 + tid] = sh.keys[tid];
+    if ((uint32_t)tid < total) {
+        a.bin_keys[slot0 + tid] = sh.keys[tid];
+        a.bin_pos[slot0 + tid] = sh.pos[tid];
+    }
     {
         uint4 *dst = reinterpret_cast<uint4 *>(a.rast + slot0);
         for (uint32_t c = (uint32_t)tid; c < 2u * total; c += kSetupThreads) dst[c] = sh.stage[c];
@@ -520,16 +572,6 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         uint4 *dst = reinterpret_cast<uint4 *>(a.shade + slot0);
         for (uint32_t c = (uint32_t)tid; c < 3u * total; c += kSetupThreads) dst[c] = sh.stage[c];
     }
-    // wave-aggregated tile counting: one atomic per distinct tile per wave
-    unsigned long long pending = __ballot(single);
-    while (pending) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
-        const uint32_t lt = __builtin_amdgcn_readlane(tile, leader);
-        const unsigned long long same = __ballot(single && tile == lt);
-        if (lane == leader) atomicAdd(&a.tile_count[lt], (uint32_t)__popcll(same));
-        pending &= ~same;
-    }
-    if (state == FAST && !single) count_box(a, st);
 
     // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
     // order) and are queued for k_clip ----
@@ -547,7 +589,8 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
 
 constexpr uint32_t kBlocksPerGroup = 1; // work items one setup workgroup takes, one after the other
 
-__global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
+// (six resident waves per SIMD matter more to this kernel than the last few registers)
+__global__ __launch_bounds__(kSetupThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_setup(SetupArgs a)
 {
     __shared__ SetupShared sh;
     const uint32_t first = blockIdx.x * kBlocksPerGroup, last = min(first + kBlocksPerGroup, a.n_blocks);
@@ -628,7 +671,13 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
 constexpr int kOrderClasses = 128;
 __device__ inline uint32_t order_class(uint32_t count) { return min((count + 15u) >> 4, (uint32_t)kOrderClasses - 1u); }
 
-// Workgroup 0: exclusive scan of the per-tile bin counts (eight counts per thread and round).
+__device__ inline uint32_t bin_size(const ScanArgs &a, uint32_t i)
+{
+    const uint4 t = reinterpret_cast<const uint4 *>(a.tiles)[i]; // front, back, multi, off
+    return t.x + t.y + t.z;
+}
+
+// Workgroup 0: bin size of every tile and their exclusive scan (eight tiles per thread and round).
 // Workgroup 1: total number of surviving triangles.
 // Workgroup 2: launch order of the tiles.
 __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
@@ -642,7 +691,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         __shared__ uint32_t s_hist[kOrderClasses];
         if (tid < kOrderClasses) s_hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(a.tile_count[i])], 1u);
+        for (uint32_t i = tid; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(bin_size(a, i))], 1u);
         __syncthreads();
         if (tid == 0) {
             uint32_t run = 0;
@@ -654,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         }
         __syncthreads();
         for (uint32_t i = tid; i < a.n_tiles; i += 1024)
-            a.tile_order[atomicAdd(&s_hist[order_class(a.tile_count[i])], 1u)] = i;
+            a.tile_order[atomicAdd(&s_hist[order_class(bin_size(a, i))], 1u)] = i;
         return;
     }
     if (blockIdx.x == 1) {
@@ -676,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         const uint32_t i0 = base + 8u * (uint32_t)tid;
         uint32_t v[8], sum = 0;
         for (int k = 0; k < 8; ++k) {
-            v[k] = (i0 + k < a.n_tiles) ? a.tile_count[i0 + k] : 0u;
+            v[k] = (i0 + k < a.n_tiles) ? bin_size(a, i0 + k) : 0u;
             sum += v[k];
         }
         const uint32_t incl = wave_inclusive_scan(sum, lane);
@@ -691,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         const uint32_t carry = s_carry;
         uint32_t run = carry + wbase + incl - sum;
         for (int k = 0; k < 8; ++k) {
-            if (i0 + k < a.n_tiles) a.tile_off[i0 + k] = run;
+            if (i0 + k < a.n_tiles) a.tiles[i0 + k].off = run;
             run += v[k];
         }
         __syncthreads();
@@ -713,103 +762,66 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // whose pixel box inside the tile holds at most kSmallBox pixels are stored from the front of the
 // tile's range, the others from its back, so that the raster kernel meets boxes of similar size
 // next to each other.  The order of entries inside a bin is irrelevant to the image.
-// A wave files 64 records in two steps so that the memory round trips of several such rounds
-// overlap: `bin_reserve` groups the lanes by key and lets every group leader reserve the group's
-// run of bin entries (one atomic per group), `bin_store` writes the slot numbers once the
-// reservations have come back.  A key is a kBinKey* value or 2 * tile + class.
-struct BinTicket {
-    uint32_t base;   // reserved start of the group, valid in the group's leader lane
-    uint32_t off, count; // the tile's bin range
-    int leader;
-    uint32_t rank;
-};
-
-__device__ inline BinTicket bin_reserve(const BinArgs &a, bool valid, uint32_t key, int lane)
+// Triangles that lie in one tile come with their position inside the bin (reserved by k_setup):
+// filing them is one store.  Triangles that span several tiles take one entry at the back of each
+// of those bins here.  A key is a kBinKey* value or 2 * tile + class.
+__device__ inline void bin_file(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p)
 {
-    const bool single = valid && key < kBinKeyBlock;
-    const uint32_t tile = key >> 1;
-    BinTicket t;
-    t.base = 0; t.off = 0; t.count = 0; t.leader = lane; t.rank = 0;
-    // group the lanes of the wave by (tile, class) without touching memory ...
-    unsigned long long pending = __ballot(single);
-    uint32_t my_count = 0;
-    while (pending) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
-        const uint32_t lk = __builtin_amdgcn_readlane(key, leader);
-        const bool mine = single && key == lk;
-        const unsigned long long same = __ballot(mine);
-        if (mine) {
-            t.leader = leader;
-            t.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            my_count = (uint32_t)__popcll(same);
-        }
-        pending &= ~same;
-    }
-    // ... then every group leader reserves its run of bin entries in one round of atomics
-    if (single) {
-        t.off = a.tile_off[tile];
-        t.count = a.tile_count[tile];
-        if (lane == t.leader) t.base = atomicAdd((key & 1u) ? &a.fill_back[tile] : &a.fill_front[tile], my_count);
-    }
-    return t;
-}
-
-__device__ inline void bin_store(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, const BinTicket &t)
-{
-    const uint32_t base = __shfl(t.base, t.leader);
     if (valid && key < kBinKeyBlock) {
-        const uint32_t p = base + t.rank;
-        a.bins[(key & 1u) ? t.off + t.count - 1u - p : t.off + p] = rec;
+        const TileCtr t = a.tiles[key >> 1];
+        a.bins[(key & 1u) ? t.off + bin_size(t) - 1u - p : t.off + p] = rec;
     }
+    if (a.debug & kDebugSkipLarge) return; // development: single-tile triangles only
+    uint32_t cols = 0, rows = 0, first = 0;
+    bool walk = false; // the triangle takes its entries itself, tile by tile
     if (valid && (key & 0xC0000000u) == kBinKeyBlock) {
-        // a block of tiles: the reservations of its first four tiles travel together
-        const uint32_t cols = ((key >> 21) & 15u) + 1u, rows = ((key >> 25) & 15u) + 1u, n_t = cols * rows;
-        const uint32_t first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
-        const bool big = (key >> 29) & 1u;
-        uint32_t *fill = big ? a.fill_back : a.fill_front;
-        uint32_t pos[4], off[4], cnt[4];
-        uint32_t cx = 0, cy = 0;
+        cols = ((key >> 21) & 15u) + 1u;
+        rows = ((key >> 25) & 15u) + 1u;
+        first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
+        if (cols * rows <= 4u) {
+            // up to four tiles: k_setup reserved the entries at the back of their bins
+            const uint4 p4 = a.bin_pos4[rec];
+            const uint32_t given[4] = {p4.x, p4.y, p4.z, p4.w};
+            uint32_t cx = 0, cy = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < n_t) {
-                const uint32_t tl = first + cy * a.g.tiles_x + cx;
-                off[j] = a.tile_off[tl];
-                cnt[j] = a.tile_count[tl];
-                pos[j] = atomicAdd(&fill[tl], 1u);
-                if (++cx == cols) { cx = 0; ++cy; }
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if ((uint32_t)j < n_t) a.bins[big ? off[j] + cnt[j] - 1u - pos[j] : off[j] + pos[j]] = rec;
-        for (uint32_t j = 4; j < n_t; ++j) {
-            const uint32_t tl = first + cy * a.g.tiles_x + cx;
-            const uint32_t o = a.tile_off[tl], n = a.tile_count[tl];
-            const uint32_t p = atomicAdd(&fill[tl], 1u);
-            a.bins[big ? o + n - 1u - p : o + p] = rec;
-            if (++cx == cols) { cx = 0; ++cy; }
+            for (int j = 0; j < 4; ++j)
+                if ((uint32_t)j < cols * rows) {
+                    const TileCtr t = a.tiles[first + cy * a.g.tiles_x + cx];
+                    a.bins[t.off + bin_size(t) - 1u - given[j]] = rec;
+                    if (++cx == cols) { cx = 0; ++cy; }
+                }
+        } else {
+            walk = true;
         }
     }
     if (valid && key == kBinKeyFromRecord) {
         const RastRec r = a.rast[rec];
-        if (r.x0 == kNoRaster) return;
-        const Tri t = unpack_tri(r, a.wide, rec);
-        int32_t bx0, bx1, by0, by1;
-        if (!pixel_box(t, 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1)) return;
-        const int32_t tx0 = bx0 / kTile, tx1 = bx1 / kTile, ty0 = by0 / kTile, ty1 = by1 / kTile;
-        for (int32_t ty = ty0; ty <= ty1; ++ty)
-            for (int32_t tx = tx0; tx <= tx1; ++tx) {
-                const uint32_t tl = (uint32_t)(ty - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx;
-                const int32_t w = min(bx1, tx * kTile + kTile - 1) - max(bx0, tx * kTile) + 1;
-                const int32_t h = min(by1, ty * kTile + kTile - 1) - max(by0, ty * kTile) + 1;
-                const uint32_t off = a.tile_off[tl];
-                if (w * h > kSmallBox) {
-                    const uint32_t p = atomicAdd(&a.fill_back[tl], 1u);
-                    a.bins[off + a.tile_count[tl] - 1u - p] = rec;
-                } else {
-                    const uint32_t p = atomicAdd(&a.fill_front[tl], 1u);
-                    a.bins[off + p] = rec;
-                }
-            }
+        int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+        if (r.x0 != kNoRaster &&
+            pixel_box(unpack_tri(r, a.wide, rec), 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1)) {
+            cols = (uint32_t)(bx1 / kTile - bx0 / kTile) + 1u;
+            rows = (uint32_t)(by1 / kTile - by0 / kTile) + 1u;
+            first = (uint32_t)(by0 / kTile - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)(bx0 / kTile);
+            walk = true;
+        }
+    }
+    // The wave takes such triangles one at a time and spreads the tiles of each over its lanes:
+    // a lane walking a large block on its own would take one memory round trip per tile.
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long todo = __ballot(walk);
+    while (todo) {
+        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const uint32_t w_cols = (uint32_t)__builtin_amdgcn_readlane((int)cols, src), w_rows = (uint32_t)__builtin_amdgcn_readlane((int)rows, src);
+        const uint32_t w_first = (uint32_t)__builtin_amdgcn_readlane((int)first, src), w_rec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
+        for (uint32_t i = (uint32_t)lane; i < w_cols * w_rows; i += 64u) {
+            const uint32_t cy = i / w_cols, cx = i - cy * w_cols;
+            const uint32_t tl = w_first + cy * a.g.tiles_x + cx;
+            const TileCtr t = a.tiles[tl];
+            // behind the reserved entries of the bin's back part
+            const uint32_t q = t.back + atomicAdd(&a.late_fill[tl], 1u);
+            a.bins[t.off + bin_size(t) - 1u - q] = w_rec;
+        }
     }
 }
 
@@ -827,37 +839,28 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blk_count[seg]);
         if (cnt == 0) return;
         // all keys of the segment are requested before the first one is used
-        uint32_t keys[kSetupThreads / 64];
+        uint32_t keys[kSetupThreads / 64], pos[kSetupThreads / 64];
 #pragma unroll
         for (int k = 0; k < kSetupThreads / 64; ++k) {
             const uint32_t i = 64u * k + (uint32_t)lane;
             keys[k] = i < cnt ? a.bin_keys[seg * kSetupThreads + i] : kBinKeyNone;
+            pos[k] = i < cnt ? a.bin_pos[seg * kSetupThreads + i] : 0u;
         }
         if (a.debug & kDebugSkipSmall) { // development: stop after the loads
-            if ((keys[0] ^ keys[1] ^ keys[2] ^ keys[3]) == 0x12345678u) a.bins[0] = 0;
-            return;
-        }
-        BinTicket tickets[kSetupThreads / 64];
-#pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k)
-            if (64u * k < cnt) tickets[k] = bin_reserve(a, 64u * k + (uint32_t)lane < cnt, keys[k], lane);
-        if (a.debug & kDebugSkipLarge) { // development: stop after the reservations
-            if ((tickets[0].base ^ tickets[0].off) == 0x12345678u) a.bins[0] = 0;
+            if ((keys[0] ^ keys[1] ^ keys[2] ^ keys[3] ^ pos[0]) == 0x12345678u) a.bins[0] = 0;
             return;
         }
 #pragma unroll
         for (int k = 0; k < kSetupThreads / 64; ++k)
             if (64u * k < cnt) {
                 const uint32_t i = 64u * k + (uint32_t)lane;
-                bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], tickets[k]);
+                bin_file(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k]);
             }
     } else {
         const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
         const uint32_t n_fan = a.counters->fan_records;
         if (first >= n_fan) return;
-        const bool valid = first + lane < n_fan;
-        const BinTicket t = bin_reserve(a, valid, kBinKeyFromRecord, lane);
-        bin_store(a, valid, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, t);
+        bin_file(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, 0u);
     }
 }
 

@@ -138,6 +138,17 @@ struct ObjectArgs {
     FrameGeom g;
 };
 
+// Per-tile bookkeeping of a frame.  A tile's bin is the range [off, off + front + back + multi) of
+// the bin array: entries of single-tile triangles with small pixel boxes are reserved from its
+// front (k_setup), the other reserved ones from its back (k_setup: single-tile triangles with
+// larger boxes and triangles touching up to four tiles), and behind those -- further towards the
+// front -- come the `multi` entries that k_bin places itself (triangles touching more tiles, fans
+// of clipped triangles).  `off` is filled in by k_scan.
+struct __attribute__((aligned(16))) TileCtr {
+    uint32_t front, back, multi, off;
+};
+__host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return t.front + t.back + t.multi; }
+
 struct SetupArgs {
     const sxe_vertex *vertices;
     const uint32_t *indices;
@@ -151,7 +162,9 @@ struct SetupArgs {
     uint32_t debug;            // kDebug* switches (development only)
     FrameGeom g;
     uint32_t *blk_count;       // survivors per workgroup
-    uint32_t *tile_count;
+    TileCtr *tiles;
+    uint32_t *bin_pos;         // per order slot of a single-tile triangle: its reserved position
+    uint4 *bin_pos4;           // per order slot of a triangle touching 2-4 tiles: its position in each bin's back
     RastRec *rast;
     WideRec *wide;
     ShadeRec *shade;
@@ -173,8 +186,7 @@ constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a cli
 struct ScanArgs {
     const uint32_t *blk_count;
     uint32_t n_blocks;
-    const uint32_t *tile_count;
-    uint32_t *tile_off;
+    TileCtr *tiles;            // counts as k_setup and k_clip left them; `off` is written here
     uint32_t *tile_order;      // tiles in launch order: fullest bins first
     uint32_t n_tiles;
     uint32_t bin_capacity;
@@ -189,10 +201,10 @@ struct BinArgs {
     const RastRec *rast;
     const WideRec *wide;
     const uint32_t *bin_keys;
-    const uint32_t *tile_count;
-    const uint32_t *tile_off;
-    uint32_t *fill_front;     // per tile: entries with small pixel boxes, filled upwards
-    uint32_t *fill_back;       // per tile: the others, filled downwards from the end of the bin
+    const uint32_t *bin_pos;
+    const uint4 *bin_pos4;
+    const TileCtr *tiles;
+    uint32_t *late_fill;       // per tile: how many of its `multi` entries have been placed
     uint32_t *bins;
     const FrameCounters *counters;
     uint32_t debug;            // kDebug* switches (development only; need kDebugSkipRaster as well)
@@ -200,9 +212,7 @@ struct BinArgs {
 
 struct RasterArgs {
     FrameGeom g;
-    const uint32_t *tile_count;
-    const uint32_t *tile_off;
-    const uint32_t *fill_front;
+    const TileCtr *tiles;
     const uint32_t *tile_order; // workgroup b renders tile tile_order[b]
     const uint32_t *bins;
     const RastRec *rast;

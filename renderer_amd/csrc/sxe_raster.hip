@@ -271,8 +271,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
-    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : a.tile_count[tile], off = a.tile_off[tile];
-    const uint32_t n_front = min(a.fill_front[tile], n);
+    const TileCtr ctr = a.tiles[tile];
+    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : bin_size(ctr), off = ctr.off;
+    const uint32_t n_front = min(ctr.front, n);
     // two passes over the bin: the front part holds small boxes, the back part the others
     for (int part = 0; part < 2; ++part) {
         const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
