@@ -28,7 +28,7 @@ EXPORTS = [
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
     "sxe_rotation_system", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
     "sxe_read_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
-    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_times",
+    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
     "sxe_camera_matrices",
 ]
@@ -122,7 +122,8 @@ def lib():
         L.sxe_sync.argtypes = [C.c_void_p]
         for name in ("sxe_read_color", "sxe_read_depth", "sxe_read_coverage"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
-        for name in ("sxe_read_clip_positions", "sxe_read_models", "sxe_read_transforms", "sxe_read_tile_counts", "sxe_read_tile_times"):
+        for name in ("sxe_read_clip_positions", "sxe_read_models", "sxe_read_transforms", "sxe_read_tile_counts", "sxe_read_tile_parts",
+                     "sxe_read_tile_times"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sxe_color_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
         L.sxe_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
@@ -355,6 +356,12 @@ class HipDrawer:
         n = int(self.stats()["tiles"])
         out = np.zeros(max(n, 1), dtype=np.uint32)
         self._check(self._L.sxe_read_tile_counts(self._ctx, _p(out), out.nbytes))
+        return out[:n]
+
+    def tile_parts(self):
+        n = int(self.stats()["tiles"])
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        self._check(self._L.sxe_read_tile_parts(self._ctx, _p(out), out.nbytes))
         return out[:n]
 
     def tile_times(self):

@@ -1004,6 +1004,26 @@ int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
     return SXE_OK;
 }
 
+int sxe_read_tile_parts(sxe_ctx *c, uint32_t *parts, size_t size_bytes)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    const size_t need = (size_t)c->g.n_tiles * 12;
+    if (!parts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
+    rc = sxe_sync(c);
+    if (rc) return rc;
+    if (need) {
+        std::vector<TileCtr> ctr(c->g.n_tiles);
+        SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ctr.size(); ++i) {
+            parts[3 * i] = ctr[i].front;
+            parts[3 * i + 1] = ctr[i].back;
+            parts[3 * i + 2] = ctr[i].multi;
+        }
+    }
+    return SXE_OK;
+}
+
 int sxe_read_tile_times(sxe_ctx *c, uint64_t *clocks, size_t size_bytes)
 {
     int rc = check_ctx(c);

@@ -37,7 +37,12 @@ static hipError_t ensure_tables()
     return hipSuccess;
 }
 
-constexpr int kWideQueue = 512;   // wide-box entries of one tile that all four waves share
+constexpr int kWideQueue = 128;   // wide-box entries of one tile that all four waves share
+struct WideEntry {                // a queued triangle: corners, depth plane, submission order
+    int32_t x0, y0, x1, y1, x2, y2;
+    float z0, dz1, dz2;
+    uint32_t order;
+};
 constexpr int kTexCache = 64;     // texture descriptors kept in LDS
 constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
 constexpr int kEntriesPerLane = 2; // bin entries a lane fetches together
@@ -118,8 +123,9 @@ __device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint
 {
     if (z < 1.0f) { // a depth of 1.0 can never be Less than the cleared 1.0
         const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | order;
-        unsigned long long *p = &vis[pix];
-        if (key < *p) atomicMin(p, key);
+        // no read first: the LDS read would have to come back before the lane can go on, the
+        // atomic does not
+        atomicMin(&vis[pix], key);
     }
 }
 
@@ -164,6 +170,8 @@ struct WideSetup {
     int32_t qx0, qy0;
     uint32_t bw, cnt, magic;              // idx / bw == (idx * magic) >> 16 for idx < 1024, bw <= 32
     bool is_narrow;
+    long long W0, W1, W2;                 // the same edge functions in 64 bits (triangles that are not narrow)
+    bool misses;                          // an edge has the whole box on its outside: nothing to draw here
 };
 
 __device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
@@ -185,6 +193,16 @@ __device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, i
     w.bw = (uint32_t)(bx1 - bx0 + 1);
     w.cnt = w.bw * (uint32_t)(by1 - by0 + 1);
     w.magic = (65536u + w.bw - 1u) / w.bw;
+    w.W0 = (long long)w.ex0 * (long long)(sy - t.y1) - (long long)w.ey0 * (long long)(sx - t.x1) - edge_bias(w.ex0, w.ey0);
+    w.W1 = (long long)w.ex1 * (long long)(sy - t.y2) - (long long)w.ey1 * (long long)(sx - t.x2) - w.b1;
+    w.W2 = (long long)w.ex2 * (long long)(sy - t.y0) - (long long)w.ey2 * (long long)(sx - t.x0) - w.b2;
+    // The box is the triangle's bounding box cut to the tile, and a large triangle leaves much of
+    // that empty.  An edge function is linear, so its largest value over the box is at a corner.
+    const long long sx_span = 256ll * (long long)(bx1 - bx0), sy_span = 256ll * (long long)(by1 - by0);
+    const long long m0 = w.W0 + max(0ll, -(long long)w.ey0 * sx_span) + max(0ll, (long long)w.ex0 * sy_span);
+    const long long m1 = w.W1 + max(0ll, -(long long)w.ey1 * sx_span) + max(0ll, (long long)w.ex1 * sy_span);
+    const long long m2 = w.W2 + max(0ll, -(long long)w.ey2 * sx_span) + max(0ll, (long long)w.ex2 * sy_span);
+    w.misses = (m0 | m1 | m2) < 0;
     return w;
 }
 
@@ -218,21 +236,23 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
             }
         }
     } else {
-        const long long x0 = SXE_RL(t.x0), y0 = SXE_RL(t.y0), x1 = SXE_RL(t.x1), y1 = SXE_RL(t.y1), x2 = SXE_RL(t.x2), y2 = SXE_RL(t.y2);
-        const long long ex0 = x2 - x1, ey0 = y2 - y1, ex1 = x0 - x2, ey1 = y0 - y2, ex2 = x1 - x0, ey2 = y1 - y0;
-        const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
-                        b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
+        // 64-bit edge functions at the box origin plus 32 x 32 -> 64 bit steps from there
+        const long long W0 = ((long long)SXE_RL((int)(w.W0 >> 32)) << 32) | (unsigned int)SXE_RL((int)(unsigned int)w.W0);
+        const long long W1 = ((long long)SXE_RL((int)(w.W1 >> 32)) << 32) | (unsigned int)SXE_RL((int)(unsigned int)w.W1);
+        const long long W2 = ((long long)SXE_RL((int)(w.W2 >> 32)) << 32) | (unsigned int)SXE_RL((int)(unsigned int)w.W2);
+        const int32_t ex0 = SXE_RL(w.ex0), ey0 = SXE_RL(w.ey0), ex1 = SXE_RL(w.ex1), ey1 = SXE_RL(w.ey1), ex2 = SXE_RL(w.ex2), ey2 = SXE_RL(w.ey2);
+        const long long b1 = SXE_RL(w.b1), b2 = SXE_RL(w.b2);
         for (uint32_t idx = first; idx < cnt; idx += stride) {
             const uint32_t row = __umul24(idx, magic) >> 16;
-            const int32_t i = qx0 + (int32_t)(idx - __umul24(row, bw)), j = qy0 + (int32_t)row;
-            const long long sx = 256 * i + 128, sy = 256 * j + 128;
-            const long long E0 = ex0 * (sy - y1) - ey0 * (sx - x1);
-            const long long E1 = ex1 * (sy - y2) - ey1 * (sx - x2);
-            const long long E2 = ex2 * (sy - y0) - ey2 * (sx - x0);
-            if (((E0 - b0) | (E1 - b1) | (E2 - b2)) >= 0) {
-                const float l1 = (float)E1 * rA, l2 = (float)E2 * rA;
+            const int32_t di = (int32_t)(idx - __umul24(row, bw)), dj = (int32_t)row;
+            const int32_t sx = 256 * di, sy = 256 * dj;
+            const long long E0 = W0 + (long long)ex0 * (long long)sy - (long long)ey0 * (long long)sx;
+            const long long E1 = W1 + (long long)ex1 * (long long)sy - (long long)ey1 * (long long)sx;
+            const long long E2 = W2 + (long long)ex2 * (long long)sy - (long long)ey2 * (long long)sx;
+            if ((E0 | E1 | E2) >= 0) {
+                const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
                 const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
-                depth_min(vis, (j - tpy) * kTile + (i - tpx), z, order);
+                depth_min(vis, (qy0 + dj - tpy) * kTile + (qx0 + di - tpx), z, order);
             }
         }
     }
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     __shared__ float s_thr[256];
     __shared__ float s_dec[256];
     __shared__ TexDev s_tex[kTexCache];
-    __shared__ uint32_t s_wq[kWideQueue];
+    __shared__ WideEntry s_wq[kWideQueue];
     __shared__ uint32_t s_nwq, s_ncov;
     __shared__ uint16_t s_cov[kTilePixels]; // tile-local indices of the covered pixels
     // the frame's counters are final by now: report them to the host without a copy command
@@ -316,7 +336,11 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                     // boxes too large for one lane are shared by all four waves after this pass
                     const uint32_t qi = atomicAdd(&s_nwq, 1u);
                     if (qi < kWideQueue) {
-                        s_wq[qi] = slot;
+                        // the whole triangle, so that the second pass needs no memory access
+                        WideEntry q;
+                        q.x0 = t.x0; q.y0 = t.y0; q.x1 = t.x1; q.y1 = t.y1; q.x2 = t.x2; q.y2 = t.y2;
+                        q.z0 = r.z0; q.dz1 = r.dz1; q.dz2 = r.dz2; q.order = r.order;
+                        s_wq[qi] = q;
                         wide_box = false;
                     }
                 }
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
             unsigned long long lm = __ballot(wide_box);
             if (lm) {
                 const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
+                lm = __ballot(wide_box && !ws.misses);
                 while (lm) {
                     const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
                     lm &= lm - 1;
@@ -348,13 +373,13 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
             Tri t = {0, 0, 0, 0, 0, 0};
             int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
             if (valid) {
-                const uint32_t slot = s_wq[e];
-                r = a.rast[slot];
-                t = unpack_tri(r, a.wide, slot);
+                const WideEntry q = s_wq[e];
+                t.x0 = q.x0; t.y0 = q.y0; t.x1 = q.x1; t.y1 = q.y1; t.x2 = q.x2; t.y2 = q.y2;
+                r.z0 = q.z0; r.dz1 = q.dz1; r.dz2 = q.dz2; r.order = q.order;
                 pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
             }
             const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
-            unsigned long long lm = __ballot(valid);
+            unsigned long long lm = __ballot(valid && !ws.misses);
             while (lm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
                 lm &= lm - 1;

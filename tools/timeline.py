@@ -10,7 +10,7 @@ with api.HipDrawer(w, h, timing=True, debug_flags=(1 << 26)) as d:
     d.update_scene(s); d.update_camera(s.camera)
     for i in range(3):
         d.rotation_system(3, i, 16.0); d.draw(0); d.sync()
-    tt = d.tile_times().astype(np.int64); tc = d.tile_counts().astype(np.int64)
+    tt = d.tile_times().astype(np.int64); tc = d.tile_counts().astype(np.int64); tp = d.tile_parts().astype(np.float64)
     print(d.timings())
 t0 = tt[:, 0].min()
 st = (tt[:, 0] - t0) / 100.0; en = (tt[:, 7] - t0) / 100.0; du = en - st   # microseconds
@@ -33,3 +33,7 @@ for title, sel in (("last finishing", np.argsort(en)[-8:]), ("longest", np.argso
 A = np.vstack([np.ones_like(tc), tc]).T.astype(float)
 coef = np.linalg.lstsq(A, du, rcond=None)[0]
 print("fit: dur = %.2f us + %.4f us * entries" % tuple(coef))
+A3 = np.hstack([np.ones((len(tp), 1)), tp])
+c3 = np.linalg.lstsq(A3, du, rcond=None)[0]
+print("fit: dur = %.2f us + %.4f * front + %.4f * back + %.4f * multi; residual rms %.2f us (entries-only fit: %.2f us)" % (
+    *c3, np.sqrt(np.mean((A3 @ c3 - du) ** 2)), np.sqrt(np.mean((A @ coef - du) ** 2))))
