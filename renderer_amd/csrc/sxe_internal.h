@@ -205,6 +205,8 @@ struct BinArgs {
     const uint4 *bin_pos4;
     const TileCtr *tiles;
     uint32_t *late_fill;       // per tile: how many of its `multi` entries have been placed
+    const uint32_t *tile_order;
+    uint4 *tile_launch;        // per launch position: tile, bin offset, bin size, front entries
     uint32_t *bins;
     const FrameCounters *counters;
     uint32_t debug;            // kDebug* switches (development only; need kDebugSkipRaster as well)
@@ -212,8 +214,7 @@ struct BinArgs {
 
 struct RasterArgs {
     FrameGeom g;
-    const TileCtr *tiles;
-    const uint32_t *tile_order; // workgroup b renders tile tile_order[b]
+    const uint4 *tile_launch;   // workgroup b renders tile tile_launch[b].x; .y bin offset, .z bin size, .w front entries
     const uint32_t *bins;
     const RastRec *rast;
     const WideRec *wide;

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     if (a.counters->overflow) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_order[blockIdx.x]);
+    const uint4 launch = a.tile_launch[blockIdx.x]; // tile, bin offset, bin size, front entries
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
-    const TileCtr ctr = a.tiles[tile];
-    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : bin_size(ctr), off = ctr.off;
-    const uint32_t n_front = min(ctr.front, n);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y);
+    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z);
+    const uint32_t n_front = min((uint32_t)__builtin_amdgcn_readfirstlane((int)launch.w), n);
     // two passes over the bin: the front part holds small boxes, the back part the others
     for (int part = 0; part < 2; ++part) {
         const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
