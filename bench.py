@@ -119,11 +119,12 @@ def main():
             drawer.rotation_system(SEED, frame_no[0], DELTA_MS)
             frame_no[0] += 1
         else:
-            # frame-parallel: this rank renders frame (i*world + rank); replay the skipped updates
+            # frame-parallel: this rank renders frame (i*world + rank); the updates of the frames
+            # the other ranks render are applied in the same launch
             target = i * world + rank
-            while frame_no[0] <= target:
-                drawer.rotation_system(SEED, frame_no[0], DELTA_MS)
-                frame_no[0] += 1
+            if frame_no[0] <= target:
+                drawer.rotation_system(SEED, frame_no[0], DELTA_MS, n_frames=target - frame_no[0] + 1)
+                frame_no[0] = target + 1
         drawer.update_camera(scene.camera)
         drawer.draw(i & 1)
         if sortfirst:

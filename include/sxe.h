@@ -151,6 +151,9 @@ int sxe_update_transforms(sxe_ctx *ctx, const sxe_transform *transforms, uint32_
 /* Rotation::run (src/systems/rotation.rs:26-37) on the device-resident transforms, with a
  * counter-based PRNG in place of thread_rng and a caller-supplied frame delta in ms. */
 int sxe_rotation_system(sxe_ctx *ctx, uint64_t seed, uint32_t frame, float delta_ms);
+/* The same for n_frames consecutive frames in one launch (identical arithmetic, applied in frame
+ * order): what a process that renders only every N-th frame of an animation needs. */
+int sxe_rotation_system_span(sxe_ctx *ctx, uint64_t seed, uint32_t first_frame, uint32_t n_frames, float delta_ms);
 /* Drawer::update_camera (src/renderer/drawer.rs:507-518). */
 int sxe_update_camera(sxe_ctx *ctx, const sxe_transform *camera);
 /* The same upload with caller-built matrices (column-major view, proj). */

@@ -26,7 +26,7 @@ E_INVALID, E_DEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4
 EXPORTS = [
     "sxe_default_config", "sxe_create", "sxe_destroy", "sxe_last_error", "sxe_version", "sxe_set_textures",
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
-    "sxe_rotation_system", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
+    "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
     "sxe_read_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
     "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
@@ -116,6 +116,7 @@ def lib():
         L.sxe_update_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sxe_update_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sxe_rotation_system.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_float]
+        L.sxe_rotation_system_span.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float]
         L.sxe_update_camera.argtypes = [C.c_void_p, C.c_void_p]
         L.sxe_update_camera_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sxe_draw.argtypes = [C.c_void_p, C.c_uint32]
@@ -298,8 +299,12 @@ class HipDrawer:
         t = np.ascontiguousarray(transforms, dtype=TRANSFORM)
         self._check(self._L.sxe_update_transforms(self._ctx, _p(t), len(t)))
 
-    def rotation_system(self, seed, frame, delta_ms):
-        self._check(self._L.sxe_rotation_system(self._ctx, seed, frame, delta_ms))
+    def rotation_system(self, seed, frame, delta_ms, n_frames=1):
+        """The rotation update of frames frame .. frame + n_frames - 1, in one launch."""
+        if n_frames == 1:
+            self._check(self._L.sxe_rotation_system(self._ctx, seed, frame, delta_ms))
+        else:
+            self._check(self._L.sxe_rotation_system_span(self._ctx, seed, frame, n_frames, delta_ms))
 
     def update_camera(self, transform):
         t = np.ascontiguousarray(transform, dtype=TRANSFORM).reshape(1)

@@ -831,8 +831,15 @@ int sxe_update_transforms(sxe_ctx *c, const sxe_transform *transforms, uint32_t 
 
 int sxe_rotation_system(sxe_ctx *c, uint64_t seed, uint32_t frame, float delta_ms)
 {
+    return sxe_rotation_system_span(c, seed, frame, 1, delta_ms);
+}
+
+int sxe_rotation_system_span(sxe_ctx *c, uint64_t seed, uint32_t first_frame, uint32_t n_frames, float delta_ms)
+{
+    const uint32_t frame = first_frame;
     int rc = check_ctx(c);
     if (rc) return rc;
+    if (n_frames == 0) return SXE_OK;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "rotation_system before update_drawables");
     if (!c->have_transforms) return fail(c, SXE_E_STATE, "model matrices were set directly; no transforms to rotate");
     const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
@@ -843,7 +850,7 @@ int sxe_rotation_system(sxe_ctx *c, uint64_t seed, uint32_t frame, float delta_m
     }
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev_tr[0], c->stream));
-    SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, delta_ms, c->stream));
+    SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, n_frames, delta_ms, c->stream));
     if (timing) {
         SXE_HIP(c, hipEventRecord(fs.ev_tr[1], c->stream));
         fs.transform_timed = true;

@@ -100,19 +100,21 @@ __global__ void k_transform_to_model(const sxe_transform *__restrict__ t, float 
     store_model(models, i, model_matrix(tr.position, tr.scale, q));
 }
 
-// Rotation::run (src/systems/rotation.rs:26-37) followed by to_ubo.
+// Rotation::run (src/systems/rotation.rs:26-37), `n_frames` consecutive updates of it, followed
+// by to_ubo.
 __global__ void k_rotation_system(sxe_transform *__restrict__ t, float *__restrict__ models, uint32_t n,
-                                  uint64_t seed, uint32_t frame, float delta_ms)
+                                  uint64_t seed, uint32_t frame, uint32_t n_frames, float delta_ms)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     sxe_transform tr = t[i];
     const float delta_time = delta_ms * 0.01f;
-    const float r = rand01(seed, frame, i);
-    const float ud = r * delta_time * 2.0f;
-    const Quat by = quat_from_euler_deg(2.0f * ud, 10.0f * ud, 20.0f * ud);
-    const Quat q0 = {tr.rotation[0], tr.rotation[1], tr.rotation[2], tr.rotation[3]};
-    const Quat q = mul(q0, by);
+    Quat q = {tr.rotation[0], tr.rotation[1], tr.rotation[2], tr.rotation[3]};
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const float r = rand01(seed, frame + f, i);
+        const float ud = r * delta_time * 2.0f;
+        q = mul(q, quat_from_euler_deg(2.0f * ud, 10.0f * ud, 20.0f * ud));
+    }
     tr.rotation[0] = q.s; tr.rotation[1] = q.x; tr.rotation[2] = q.y; tr.rotation[3] = q.z;
     t[i] = tr;
     store_model(models, i, model_matrix(tr.position, tr.scale, q));
@@ -895,10 +897,10 @@ hipError_t launch_transform_to_model(const sxe_transform *t, float *models, uint
 }
 
 hipError_t launch_rotation_system(sxe_transform *t, float *models, uint32_t n, uint64_t seed, uint32_t frame,
-                                  float delta_ms, hipStream_t s)
+                                  uint32_t n_frames, float delta_ms, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rotation_system, dim3((n + 255) / 256), dim3(256), 0, s, t, models, n, seed, frame, delta_ms);
+    if (n == 0 || n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rotation_system, dim3((n + 255) / 256), dim3(256), 0, s, t, models, n, seed, frame, n_frames, delta_ms);
     return hipGetLastError();
 }
 

@@ -238,7 +238,7 @@ struct RasterArgs {
 hipError_t launch_object(const ObjectArgs &a, hipStream_t s);
 hipError_t launch_transform_to_model(const sxe_transform *t, float *models, uint32_t n, hipStream_t s);
 hipError_t launch_rotation_system(sxe_transform *t, float *models, uint32_t n, uint64_t seed,
-                                  uint32_t frame, float delta_ms, hipStream_t s);
+                                  uint32_t frame, uint32_t n_frames, float delta_ms, hipStream_t s);
 hipError_t launch_vertex(const float *px, const float *py, const float *pz, const MeshDev *meshes,
                          const VBlockDesc *vblocks, uint32_t n_vblocks, const float *pvm,
                          float4 *clip, hipStream_t s);

@@ -117,11 +117,17 @@ def test_device_transform_kernels(orc):
             orc.rotation_system(t, 3, f, 16.0)
         assert d.read_transforms().tobytes() == t.tobytes()
         assert d.read_models().tobytes() == orc.to_model(t).tobytes()
+        # seven more updates in one launch equal seven launches
+        d.rotation_system(3, 5, 16.0, n_frames=7)
+        for f in range(5, 12):
+            orc.rotation_system(t, 3, f, 16.0)
+        assert d.read_transforms().tobytes() == t.tobytes()
+        assert d.read_models().tobytes() == orc.to_model(t).tobytes()
         d.update_camera(s.camera)
         d.draw(1)
         got = {"color": d.read_color(1), "depth": d.read_depth(1), "prim": d.read_coverage(1)}
     ref = orc.render(s, orc.to_model(t), *orc.camera(s.camera, w, h), w, h)
-    assert_frames_equal(got, ref, what="after 5 rotation steps")
+    assert_frames_equal(got, ref, what="after 12 rotation steps")
 
 
 def test_moving_camera(orc):
@@ -169,6 +175,54 @@ def test_work_buffers_grow_on_demand(orc):
     got = render_hip(s, models=models, view=IDENT, proj=IDENT)
     assert got["stats"]["redraws"] >= 1 and got["stats"]["bin_entries"] > 4096 + n // 2 + 4 * 256
     assert_frames_equal(got, ref, what="regrown buffers")
+
+
+def test_config5_views_share_one_scene(orc):
+    """The multi-view configuration: one resident scene, a new camera per 512x512 view, frames in
+    flight; the views a rank of N would render (shard.views_for_rank) are checked one by one."""
+    from renderer_amd import shard
+    s = scenes.config_scene(5, scale=0.5)
+    w, h = s.size
+    n_views, world = 12, 4
+    cams = scenes.orbit_cameras(n_views, 5, radius=30.0, target=(0.0, 0.0, -22.5))
+    models = orc.to_model(s.transforms)
+    for rank in (0, 3):
+        mine = list(range(*shard.views_for_rank(n_views, world, rank)))
+        assert len(mine) == 3
+        with api.HipDrawer(w, h, n_images=len(mine), coverage=True) as d:
+            d.update_scene(s)
+            for k, v in enumerate(mine):
+                d.update_camera(cams[v:v + 1])
+                d.draw(k)
+            d.sync()
+            for k, v in enumerate(mine):
+                view, proj = orc.camera(cams[v:v + 1], w, h)
+                ref = orc.render(s, models, view, proj, w, h)
+                got = {"color": d.read_color(k), "depth": d.read_depth(k), "prim": d.read_coverage(k)}
+                assert_frames_equal(got, ref, what="view %d (rank %d)" % (v, rank))
+
+
+def test_config4_bands_of_an_8k_aspect_frame(orc):
+    """The sort-first configuration at reduced size: 8 bands of whole tile rows of a 16:9 frame whose
+    height is not a multiple of the tile size reassemble to the full frame."""
+    from renderer_amd import shard
+    s = scenes.config_scene(4, scale=0.05)  # 384 x 216, 500 objects
+    w, h = s.size
+    ref = orc.render(s, orc.to_model(s.transforms), *orc.camera(s.camera, w, h), w, h)
+    color = np.zeros((h, w, 4), np.uint8)
+    depth = np.zeros((h, w), np.float32)
+    covered = np.zeros(h, bool)
+    for rank in range(8):
+        y0, y1 = shard.band_rows(h, 8, rank)
+        if y1 <= y0:
+            continue
+        got = render_hip(s, scissor=(y0, y1))
+        color[y0:y1] = got["color"][y0:y1]
+        depth[y0:y1] = got["depth"][y0:y1]
+        assert not covered[y0:y1].any()
+        covered[y0:y1] = True
+    assert covered.all()
+    assert np.array_equal(color, ref["color"]) and np.array_equal(depth.view(np.uint32), ref["depth"].view(np.uint32))
 
 
 def test_frames_in_flight(orc):
