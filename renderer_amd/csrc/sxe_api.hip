@@ -398,7 +398,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     {
         ObjectArgs oa = object_args(c, fs);
         oa.objects = fresh ? 1u : 0u;
-        oa.n_zero = (uint32_t)(5 * ntc); // the TileCtr of every tile, then the late-fill counters
+        oa.n_zero = (uint32_t)(9 * ntc); // the TileCtr of every tile (8 words), then the late-fill counters
         SXE_HIP(c, launch_object(oa, s));
     }
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_OBJECT], s));
@@ -435,7 +435,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sc.blk_count = c->blk_count.p;
     sc.n_blocks = c->n_blocks;
     sc.tiles = sa.tiles;
-    sc.tile_order = c->tile_counters.p + 5 * ntc;
+    sc.tile_order = c->tile_counters.p + 9 * ntc;
     sc.n_tiles = nt;
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
     sc.counters = c->counters.p;
@@ -453,7 +453,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.bin_pos = c->bin_pos.p;
     ba.bin_pos4 = c->bin_pos4.p;
     ba.tiles = sa.tiles;
-    ba.late_fill = c->tile_counters.p + 4 * ntc;
+    ba.late_fill = c->tile_counters.p + 8 * ntc;
     ba.tile_order = sc.tile_order;
     ba.tile_launch = c->tile_launch.p;
     ba.bins = c->bins.p;
@@ -700,7 +700,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(6 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_counters.reserve(10 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_launch.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile launch records)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
@@ -1025,8 +1025,8 @@ int sxe_read_tile_parts(sxe_ctx *c, uint32_t *parts, size_t size_bytes)
         std::vector<TileCtr> ctr(c->g.n_tiles);
         SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ctr.size(); ++i) {
-            parts[3 * i] = ctr[i].front;
-            parts[3 * i + 1] = ctr[i].back;
+            parts[3 * i] = ctr[i].cnt[0] + ctr[i].cnt[1];
+            parts[3 * i + 1] = ctr[i].cnt[2] + ctr[i].cnt[3];
             parts[3 * i + 2] = ctr[i].multi;
         }
     }

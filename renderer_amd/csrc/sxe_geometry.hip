@@ -473,13 +473,13 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
     const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
     const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
-    const bool big = (st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1) > kSmallBox;
-    // A triangle that touches up to four tiles reserves an entry at the back of each of those
-    // bins as well; larger ones are only counted and take their entries in k_bin.
+    const uint32_t part = size_class((uint32_t)((st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1)), narrow(st.t));
+    // A triangle that touches up to four tiles reserves an entry in each of those bins as well;
+    // larger ones are only counted and take their entries in k_bin.
     const uint32_t cols_m1 = (uint32_t)(st.px1 / kTile - tx0), rows_m1 = (uint32_t)(st.py1 / kTile - ty0);
     const uint32_t n_touched = (cols_m1 + 1u) * (rows_m1 + 1u);
     const bool few = (state == FAST) && !single && n_touched <= 4u;
-    // Entry j of a lane goes to the counter 2 * tile + part (part 1: the back of the bin).  The
+    // Entry j of a lane goes to the counter 4 * tile + size class.  The
     // lanes of the wave whose entry j names the same counter share one atomic: neighbouring
     // triangles fall into the same tiles, and a reservation that many lanes make on one counter
     // one after the other is slow to come back.
@@ -491,7 +491,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool has = (j == 0 && single) || (few && (uint32_t)j < n_touched);
-            const uint32_t counter = 2u * (first + cy * a.g.tiles_x + cx) + ((single && !big) ? 0u : 1u);
+            const uint32_t counter = 4u * (first + cy * a.g.tiles_x + cx) + part;
             uint32_t count_j = 0;
             who4[j] = (uint32_t)lane;
             unsigned long long pending = __ballot(has);
@@ -506,10 +506,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
                 }
                 pending &= ~same;
             }
-            if (has && (uint32_t)lane == (who4[j] & 255u)) {
-                TileCtr &tc = a.tiles[counter >> 1];
-                raw4[j] = atomicAdd((counter & 1u) ? &tc.back : &tc.front, count_j);
-            }
+            if (has && (uint32_t)lane == (who4[j] & 255u)) raw4[j] = atomicAdd(&a.tiles[counter >> 2].cnt[counter & 3u], count_j);
             if (++cx > cols_m1) { cx = 0; ++cy; }
         }
     }
@@ -546,10 +543,10 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         sh.pos[local] = bin_pos;
         const uint32_t cols = cols_m1, rows = rows_m1;
         const uint32_t block_key = (cols < 16u && rows < 16u)
-                                       ? kBinKeyBlock | (big ? 1u << 29 : 0u) | (rows << 25) | (cols << 21) |
+                                       ? kBinKeyBlock | (part << 28) | (rows << 24) | (cols << 20) |
                                              ((uint32_t)(ty0 - (int32_t)a.g.tile_row0) << 8) | (uint32_t)tx0
                                        : kBinKeyFromRecord;
-        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 2u + (big ? 1u : 0u) : block_key);
+        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 4u + part : block_key);
         uint4 *sr = sh.stage, *ss = sh.stage + 2 * kSetupThreads; // raster records, then shading records
         sr[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
         sr[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), r.order);
@@ -670,8 +667,7 @@ __device__ inline uint32_t order_class(uint32_t count) { return min((count + 15u
 
 __device__ inline uint32_t bin_size(const ScanArgs &a, uint32_t i)
 {
-    const uint4 t = reinterpret_cast<const uint4 *>(a.tiles)[i]; // front, back, multi, off
-    return t.x + t.y + t.z;
+    return bin_size(a.tiles[i]);
 }
 
 // Expected running time of a tile's workgroup, in units of one small-box entry: measured tile
@@ -679,8 +675,8 @@ __device__ inline uint32_t bin_size(const ScanArgs &a, uint32_t i)
 // more than four tiles.
 __device__ inline uint32_t tile_cost(const ScanArgs &a, uint32_t i)
 {
-    const uint4 t = reinterpret_cast<const uint4 *>(a.tiles)[i]; // front, back, multi, off
-    return (t.x + 3u * t.y + 100u * t.z) >> 2;
+    const TileCtr t = a.tiles[i];
+    return (t.cnt[0] + t.cnt[1] + 3u * t.cnt[2] + 5u * t.cnt[3] + 100u * t.multi) >> 2;
 }
 
 // Workgroup 0: bin size of every tile and their exclusive scan (eight tiles per thread and round).
@@ -697,7 +693,16 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         __shared__ uint32_t s_hist[kOrderClasses];
         if (tid < kOrderClasses) s_hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u);
+        // (a thread keeps the classes of its first eight tiles: frames up to 8192 tiles read the
+        // counters once)
+        uint32_t mine[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = (uint32_t)tid + 1024u * (uint32_t)k;
+            mine[k] = i < a.n_tiles ? order_class(tile_cost(a, i)) : 0u;
+            if (i < a.n_tiles) atomicAdd(&s_hist[mine[k]], 1u);
+        }
+        for (uint32_t i = tid + 8192u; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u);
         __syncthreads();
         if (tid == 0) {
             uint32_t run = 0;
@@ -708,7 +713,12 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
             }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < a.n_tiles; i += 1024)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = (uint32_t)tid + 1024u * (uint32_t)k;
+            if (i < a.n_tiles) a.tile_order[atomicAdd(&s_hist[mine[k]], 1u)] = i;
+        }
+        for (uint32_t i = tid + 8192u; i < a.n_tiles; i += 1024)
             a.tile_order[atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u)] = i;
         return;
     }
@@ -764,36 +774,40 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // Binning
 // ------------------------------------------------------------------------------------------
 
-// Reads the surviving records back and scatters their slot numbers into the tile bins.  Entries
-// whose pixel box inside the tile holds at most kSmallBox pixels are stored from the front of the
-// tile's range, the others from its back, so that the raster kernel meets boxes of similar size
-// next to each other.  The order of entries inside a bin is irrelevant to the image.
-// Triangles that lie in one tile come with their position inside the bin (reserved by k_setup):
-// filing them is one store.  Triangles that span several tiles take one entry at the back of each
-// of those bins here.  A key is a kBinKey* value or 2 * tile + class.
+// Scatters the slot numbers of the surviving triangles into the tile bins.  The order of entries
+// inside a bin is irrelevant to the image; they are laid out by size class so that the tile kernel
+// meets boxes of similar size next to each other.
+// Triangles that touch up to four tiles come with their positions inside the size class of each
+// bin (reserved by k_setup): filing them is one store per tile.  Triangles that span more tiles
+// take one entry behind the reserved ones of each of those bins here.  A key is a kBinKey* value
+// or 4 * tile + size class.
+
+// First entry of size class `part` inside the tile's bin.
+__device__ inline uint32_t class_start(const TileCtr &t, uint32_t part)
+{
+    return t.off + (part > 0u ? t.cnt[0] : 0u) + (part > 1u ? t.cnt[1] : 0u) + (part > 2u ? t.cnt[2] : 0u);
+}
+
 __device__ inline void bin_file(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p)
 {
-    if (valid && key < kBinKeyBlock) {
-        const TileCtr t = a.tiles[key >> 1];
-        a.bins[(key & 1u) ? t.off + bin_size(t) - 1u - p : t.off + p] = rec;
-    }
+    if (valid && key < kBinKeyBlock) a.bins[class_start(a.tiles[key >> 2], key & 3u) + p] = rec;
     if (a.debug & kDebugSkipLarge) return; // development: single-tile triangles only
     uint32_t cols = 0, rows = 0, first = 0;
     bool walk = false; // the triangle takes its entries itself, tile by tile
     if (valid && (key & 0xC0000000u) == kBinKeyBlock) {
-        cols = ((key >> 21) & 15u) + 1u;
-        rows = ((key >> 25) & 15u) + 1u;
+        cols = ((key >> 20) & 15u) + 1u;
+        rows = ((key >> 24) & 15u) + 1u;
         first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
         if (cols * rows <= 4u) {
-            // up to four tiles: k_setup reserved the entries at the back of their bins
+            // up to four tiles: k_setup reserved the entries
+            const uint32_t part = (key >> 28) & 3u;
             const uint4 p4 = a.bin_pos4[rec];
             const uint32_t given[4] = {p4.x, p4.y, p4.z, p4.w};
             uint32_t cx = 0, cy = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if ((uint32_t)j < cols * rows) {
-                    const TileCtr t = a.tiles[first + cy * a.g.tiles_x + cx];
-                    a.bins[t.off + bin_size(t) - 1u - given[j]] = rec;
+                    a.bins[class_start(a.tiles[first + cy * a.g.tiles_x + cx], part) + given[j]] = rec;
                     if (++cx == cols) { cx = 0; ++cy; }
                 }
         } else {
@@ -824,9 +838,8 @@ __device__ inline void bin_file(const BinArgs &a, bool valid, uint32_t rec, uint
             const uint32_t cy = i / w_cols, cx = i - cy * w_cols;
             const uint32_t tl = w_first + cy * a.g.tiles_x + cx;
             const TileCtr t = a.tiles[tl];
-            // behind the reserved entries of the bin's back part
-            const uint32_t q = t.back + atomicAdd(&a.late_fill[tl], 1u);
-            a.bins[t.off + bin_size(t) - 1u - q] = w_rec;
+            // behind the reserved entries of the bin
+            a.bins[t.off + bin_reserved(t) + atomicAdd(&a.late_fill[tl], 1u)] = w_rec;
         }
     }
 }
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
         if (i < a.g.n_tiles) {
             const uint32_t tile = a.tile_order[i];
             const TileCtr t = a.tiles[tile];
-            a.tile_launch[i] = make_uint4(tile, t.off, bin_size(t), t.front);
+            a.tile_launch[i] = make_uint4(tile, t.off, bin_size(t), 0u);
         }
     }
     const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;

@@ -138,16 +138,24 @@ struct ObjectArgs {
     FrameGeom g;
 };
 
-// Per-tile bookkeeping of a frame.  A tile's bin is the range [off, off + front + back + multi) of
-// the bin array: entries of single-tile triangles with small pixel boxes are reserved from its
-// front (k_setup), the other reserved ones from its back (k_setup: single-tile triangles with
-// larger boxes and triangles touching up to four tiles), and behind those -- further towards the
-// front -- come the `multi` entries that k_bin places itself (triangles touching more tiles, fans
-// of clipped triangles).  `off` is filled in by k_scan.
+// Per-tile bookkeeping of a frame.  A tile's bin is the range [off, off + bin_size) of the bin
+// array, laid out by pixel-box size so that the lanes of a wave of the tile kernel walk boxes of
+// similar size: first the entries of size class 0, then class 1, 2, 3 (all reserved by k_setup,
+// cnt[] of them), then the `multi` entries that k_bin places itself (triangles touching more than
+// four tiles, fans of clipped triangles).  `off` is filled in by k_scan.
+constexpr int kSizeClasses = 4;
 struct __attribute__((aligned(16))) TileCtr {
-    uint32_t front, back, multi, off;
+    uint32_t cnt[kSizeClasses];
+    uint32_t multi, off, pad0, pad1;
 };
-__host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return t.front + t.back + t.multi; }
+__host__ __device__ inline uint32_t bin_reserved(const TileCtr &t) { return t.cnt[0] + t.cnt[1] + t.cnt[2] + t.cnt[3]; }
+__host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return bin_reserved(t) + t.multi; }
+// Size class of a triangle from the number of pixels in its box: <= 2, <= 8, <= 24, more
+// (triangles too large for the 32-bit edge functions always count as the last class).
+__host__ __device__ inline uint32_t size_class(uint32_t box_pixels, bool is_narrow)
+{
+    return !is_narrow ? 3u : box_pixels <= 2u ? 0u : box_pixels <= 8u ? 1u : box_pixels <= 24u ? 2u : 3u;
+}
 
 struct SetupArgs {
     const sxe_vertex *vertices;
@@ -175,10 +183,9 @@ struct SetupArgs {
     FrameCounters *counters;
 };
 
-// Bin keys: 2 * tile + (1 if the pixel box holds more than kSmallBox pixels) for a triangle whose
-// box lies in one tile; the two values below otherwise.
-// A triangle whose box spans a block of at most 16 x 16 tiles: kBinKeyBlock | class << 29 |
-// (rows - 1) << 25 | (columns - 1) << 21 | first tile row (of the rendered rows) << 8 | first column.
+// Bin keys: 4 * tile + size class for a triangle whose box lies in one tile.
+// A triangle whose box spans a block of at most 16 x 16 tiles: kBinKeyBlock | size class << 28 |
+// (rows - 1) << 24 | (columns - 1) << 20 | first tile row (of the rendered rows) << 8 | first column.
 constexpr uint32_t kBinKeyBlock = 0x80000000u;
 constexpr uint32_t kBinKeyFromRecord = 0xFFFFFFFFu; // larger blocks and fans: k_bin derives the tiles from the record
 constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a clipped triangle

@@ -294,10 +294,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 
     const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y);
     const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z);
-    const uint32_t n_front = min((uint32_t)__builtin_amdgcn_readfirstlane((int)launch.w), n);
-    // two passes over the bin: the front part holds small boxes, the back part the others
-    for (int part = 0; part < 2; ++part) {
-        const uint32_t lo = part ? n_front : 0u, hi = part ? n : n_front;
+    // the bin is laid out by box size: the 64 consecutive entries a wave takes are of similar size
+    {
+        const uint32_t lo = 0u, hi = n;
         // a wave takes kEntriesPerLane * 64 consecutive entries per round: all their slot numbers
         // are loaded together, then all their records, so a round costs two memory round trips
         for (uint32_t base = lo; base < hi; base += kRasterThreads * kEntriesPerLane) {
@@ -306,7 +305,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 #pragma unroll
           for (int k = 0; k < kEntriesPerLane; ++k) {
               const uint32_t e = base + (uint32_t)(kRasterThreads * k + tid);
-              slots[k] = e < hi ? a.bins[off + e] : 0xFFFFFFFFu;
+              // from the end of the bin: the largest boxes first, the quick ones fill the gaps
+              slots[k] = e < hi ? a.bins[off + (hi - 1u - e)] : 0xFFFFFFFFu;
           }
 #pragma unroll
           for (int k = 0; k < kEntriesPerLane; ++k) {
