@@ -18,8 +18,54 @@ namespace sxe {
 
 __constant__ float c_srgb_decode[256];
 __constant__ float c_unorm8[256];
-__constant__ float c_srgb_thr[256];
 static bool g_tables_ready[64] = {};
+
+// Linear value -> sRGB8 code = number of encode thresholds <= x.  The floats from 2^-13 (below the
+// first threshold) to 1.0 are cut into buckets that share sign, exponent and seven mantissa bits;
+// no bucket holds more than one threshold (checked when the table is built), so the code is the
+// count of thresholds below the bucket plus one comparison of the low 16 bits.
+//   entry = count << 24 | low 16 bits of the bucket's threshold (0x10000: the bucket has none)
+// Entry 0 stands for everything below 2^-13 (code 0), the last one for x >= 1 (code 255).
+constexpr int kEncKeyLo = (127 - 13) << 7;            // float bits >> 16 of 2^-13
+constexpr int kEncKeyHi = 127 << 7;                   // float bits >> 16 of 1.0
+constexpr int kEncEntries = kEncKeyHi - kEncKeyLo + 2; // 1666
+constexpr int kEncPadded = (kEncEntries + 3) & ~3;
+
+__device__ inline uint32_t srgb_encode_lds(const uint32_t *enc, float x)
+{
+    const int bits = __float_as_int(x);
+    const int idx = min(max((bits >> 16) - (kEncKeyLo - 1), 0), kEncEntries - 1);
+    const uint32_t e = enc[idx];
+    return (e >> 24) + (((uint32_t)bits & 0xFFFFu) >= (e & 0x1FFFFu) ? 1u : 0u);
+}
+
+__device__ uint4 g_srgb_encode[kEncPadded / 4];
+
+// Builds the bucket table from the threshold list; fails if a bucket would need two comparisons.
+static hipError_t upload_encode_table()
+{
+    static uint32_t table[kEncPadded];
+    auto bits_of = [](float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; };
+    if ((int)(bits_of(SXE_SRGB_ENCODE_THR[0]) >> 16) < kEncKeyLo || !(SXE_SRGB_ENCODE_THR[254] < 1.0f)) return hipErrorInvalidValue;
+    int k = 0; // thresholds below the current bucket
+    table[0] = 0x10000u;
+    for (int i = 1; i <= kEncKeyHi - kEncKeyLo; ++i) {
+        const uint32_t key = (uint32_t)(kEncKeyLo + i - 1);
+        uint32_t entry = (uint32_t)k << 24 | 0x10000u;
+        int inside = 0;
+        while (k < 255 && (bits_of(SXE_SRGB_ENCODE_THR[k]) >> 16) == key) {
+            entry = (entry & 0xFF000000u) | (bits_of(SXE_SRGB_ENCODE_THR[k]) & 0xFFFFu);
+            ++k;
+            ++inside;
+        }
+        if (inside > 1) return hipErrorInvalidValue;
+        table[i] = entry;
+    }
+    if (k != 255) return hipErrorInvalidValue;
+    for (int i = kEncEntries - 1; i < kEncPadded; ++i) table[i] = 255u << 24 | 0x10000u;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_encode), table, sizeof(table));
+}
+
 
 static hipError_t ensure_tables()
 {
@@ -27,12 +73,9 @@ static hipError_t ensure_tables()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 64 && g_tables_ready[dev]) return hipSuccess;
-    float thr[256];
-    for (int i = 0; i < 255; ++i) thr[i] = SXE_SRGB_ENCODE_THR[i];
-    thr[255] = __builtin_inff();
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_decode), SXE_SRGB_DECODE, sizeof(float) * 256)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_unorm8), SXE_UNORM8, sizeof(float) * 256)) != hipSuccess) return e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_thr), thr, sizeof(float) * 256)) != hipSuccess) return e;
+    if ((e = upload_encode_table()) != hipSuccess) return e;
     if (dev < 64) g_tables_ready[dev] = true;
     return hipSuccess;
 }
@@ -46,19 +89,6 @@ struct WideEntry {                // a queued triangle: corners, depth plane, su
 constexpr int kTexCache = 64;     // texture descriptors kept in LDS
 constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
 constexpr int kEntriesPerLane = 2; // bin entries a lane fetches together
-
-// Linear value -> sRGB8 code = number of thresholds <= x (thr[255] = +inf).  The hardware
-// log2/exp2 give a candidate within one code of the answer; two table compares make it exact, so
-// the approximation never shows in the output.
-__device__ inline uint32_t srgb_encode_lds(const float *thr, float x)
-{
-    const float y = (x <= 0.0031308f) ? 12.92f * x : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.41666666f) - 0.055f;
-    int c = (int)(y * 255.0f + 0.5f);
-    c = min(max(c, 0), 255);
-    if (c > 0 && !(thr[c - 1] <= x)) --c;
-    else if (thr[c] <= x) ++c;
-    return (uint32_t)c;
-}
 
 __device__ inline uint32_t unorm8_encode(float a)
 {
@@ -262,7 +292,7 @@ template <bool COVERAGE>
 __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
 {
     __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | order, per pixel
-    __shared__ float s_thr[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_enc[kEncPadded];
     __shared__ float s_dec[256];
     __shared__ TexDev s_tex[kTexCache];
     __shared__ WideEntry s_wq[kWideQueue];
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
     const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
     for (int i = tid; i < kTilePixels; i += kRasterThreads) vis[i] = kVisEmpty;
-    s_thr[tid] = c_srgb_thr[tid];
+    for (int i = tid; i < kEncPadded / 4; i += kRasterThreads) reinterpret_cast<uint4 *>(s_enc)[i] = g_srgb_encode[i];
     s_dec[tid] = c_srgb_decode[tid];
     if (tid < kTexCache && (uint32_t)tid < a.n_textures) s_tex[tid] = a.textures[tid];
     if (tid == 0) { s_nwq = 0; s_ncov = 0; }
@@ -548,9 +578,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_shade(RasterArgs a)
                 // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 in every
                 // shading mode (textures must be opaque, vertex colours have no alpha), and then
                 // the blend returns Cs and 1 bit for bit, so it is not evaluated.
-                const uint32_t cr = srgb_encode_lds(s_thr, src[0]);
-                const uint32_t cg = srgb_encode_lds(s_thr, src[1]);
-                const uint32_t cb = srgb_encode_lds(s_thr, src[2]);
+                const uint32_t cr = srgb_encode_lds(s_enc, src[0]);
+                const uint32_t cg = srgb_encode_lds(s_enc, src[1]);
+                const uint32_t cb = srgb_encode_lds(s_enc, src[2]);
                 code[b] = cr | (cg << 8) | (cb << 16) | 0xFF000000u;
             }
 #pragma unroll
