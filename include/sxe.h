@@ -184,9 +184,9 @@ int sxe_reset_timing_totals(sxe_ctx *ctx);
 /* Diagnostics: bin occupancy of the last frame, one count per rendered tile in row-major tile
  * order (load-balance analysis; no counterpart in the reference). */
 int sxe_read_tile_counts(sxe_ctx *ctx, uint32_t *counts, size_t size_bytes);
-/* Diagnostics: the same occupancy split into its three parts, three counts per tile: entries
- * with small pixel boxes, entries with larger boxes, entries of triangles spanning more than four
- * tiles (no counterpart in the reference). */
+/* Diagnostics: the same occupancy split into its parts, five counts per tile: entries by pixel-box
+ * size class (four classes, smallest boxes first), then entries of triangles spanning more than
+ * four tiles (no counterpart in the reference). */
 int sxe_read_tile_parts(sxe_ctx *ctx, uint32_t *parts, size_t size_bytes);
 /* Diagnostics: device clock (100 MHz) stamps of every tile's workgroup in the last frame, eight
  * values per tile (0: start, 1: after initialisation, 2-4: coverage phases, 5: compaction,

@@ -365,7 +365,7 @@ class HipDrawer:
 
     def tile_parts(self):
         n = int(self.stats()["tiles"])
-        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        out = np.zeros((max(n, 1), 5), dtype=np.uint32)
         self._check(self._L.sxe_read_tile_parts(self._ctx, _p(out), out.nbytes))
         return out[:n]
 

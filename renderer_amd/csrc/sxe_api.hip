@@ -1017,7 +1017,7 @@ int sxe_read_tile_parts(sxe_ctx *c, uint32_t *parts, size_t size_bytes)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
-    const size_t need = (size_t)c->g.n_tiles * 12;
+    const size_t need = (size_t)c->g.n_tiles * 20;
     if (!parts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     rc = sxe_sync(c);
     if (rc) return rc;
@@ -1025,9 +1025,8 @@ int sxe_read_tile_parts(sxe_ctx *c, uint32_t *parts, size_t size_bytes)
         std::vector<TileCtr> ctr(c->g.n_tiles);
         SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ctr.size(); ++i) {
-            parts[3 * i] = ctr[i].cnt[0] + ctr[i].cnt[1];
-            parts[3 * i + 1] = ctr[i].cnt[2] + ctr[i].cnt[3];
-            parts[3 * i + 2] = ctr[i].multi;
+            for (int k = 0; k < kSizeClasses; ++k) parts[5 * i + k] = ctr[i].cnt[k];
+            parts[5 * i + 4] = ctr[i].multi;
         }
     }
     return SXE_OK;

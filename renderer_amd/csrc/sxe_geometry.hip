@@ -676,7 +676,7 @@ __device__ inline uint32_t bin_size(const ScanArgs &a, uint32_t i)
 __device__ inline uint32_t tile_cost(const ScanArgs &a, uint32_t i)
 {
     const TileCtr t = a.tiles[i];
-    return (t.cnt[0] + t.cnt[1] + 3u * t.cnt[2] + 5u * t.cnt[3] + 100u * t.multi) >> 2;
+    return (t.cnt[0] + t.cnt[1] + 2u * t.cnt[2] + 8u * t.cnt[3] + 100u * t.multi) >> 2;
 }
 
 // Workgroup 0: bin size of every tile and their exclusive scan (eight tiles per thread and round).

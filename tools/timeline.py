@@ -35,5 +35,5 @@ coef = np.linalg.lstsq(A, du, rcond=None)[0]
 print("fit: dur = %.2f us + %.4f us * entries" % tuple(coef))
 A3 = np.hstack([np.ones((len(tp), 1)), tp])
 c3 = np.linalg.lstsq(A3, du, rcond=None)[0]
-print("fit: dur = %.2f us + %.4f * front + %.4f * back + %.4f * multi; residual rms %.2f us (entries-only fit: %.2f us)" % (
+print("fit: dur = %.2f us + %.4f * c0 + %.4f * c1 + %.4f * c2 + %.4f * c3 + %.4f * multi; residual rms %.2f us (entries-only fit: %.2f us)" % (
     *c3, np.sqrt(np.mean((A3 @ c3 - du) ** 2)), np.sqrt(np.mean((A @ coef - du) ** 2))))
