@@ -28,7 +28,7 @@ EXPORTS = [
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
     "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
     "sxe_read_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
-    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
+    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
     "sxe_camera_matrices",
 ]
@@ -130,6 +130,7 @@ def lib():
         L.sxe_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
         L.sxe_get_timing_totals.argtypes = [C.c_void_p, C.POINTER(Timings), C.POINTER(C.c_uint64)]
         L.sxe_reset_timing_totals.argtypes = [C.c_void_p]
+        L.sxe_set_timing_stride.argtypes = [C.c_void_p, C.c_uint32]
         L.sxe_get_stats.argtypes = [C.c_void_p, C.POINTER(FrameStats)]
         L.sxe_transform_identity.argtypes = [C.c_void_p]
         L.sxe_transform_identity.restype = None
@@ -388,6 +389,10 @@ class HipDrawer:
 
     def reset_timing_totals(self):
         self._check(self._L.sxe_reset_timing_totals(self._ctx))
+
+    def set_timing_stride(self, every):
+        """Bracket only every `every`-th frame by events (each event costs stream time)."""
+        self._check(self._L.sxe_set_timing_stride(self._ctx, int(every)))
 
     def stats(self):
         s = FrameStats()

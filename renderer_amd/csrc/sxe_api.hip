@@ -72,6 +72,7 @@ struct FrameSlot {
     hipEvent_t ev_tr[2] = {};
     hipEvent_t done = nullptr;
     bool pending = false, transform_timed = false;
+    bool timed = false; // this frame's kernels are bracketed by events
     uint32_t image = 0;
 };
 
@@ -120,6 +121,7 @@ struct sxe_ctx {
     sxe_timings timings = {};
     sxe_timings timing_totals = {};
     uint64_t timed_frames = 0;
+    uint32_t timing_stride = 1; // events are recorded for every timing_stride-th frame
     sxe_frame_stats stats = {};
     uint32_t redraws = 0;
 };
@@ -385,11 +387,17 @@ ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
     return oa;
 }
 
+// Per-kernel events cost a few microseconds each; a context may ask for them on a sample of the frames.
+static bool frame_is_timed(const sxe_ctx *c, uint64_t frame)
+{
+    return (c->cfg.flags & SXE_FLAG_TIMING) != 0 && frame % c->timing_stride == 0;
+}
+
 // Enqueues the frame of slot `fs`.  A redraw (fresh == false) keeps the slot's per-object matrices.
 int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
 {
     Image &img = c->images[fs.image];
-    const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
+    const bool timing = fs.timed;
     hipStream_t s = c->stream;
     const uint32_t nt = c->g.n_tiles;
 
@@ -558,7 +566,7 @@ int retire_oldest(sxe_ctx *c)
     if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
         fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", k.pad[0], k.pad[1],
                 k.pad[2], k.clip_count, k.fan_records);
-    if (c->cfg.flags & SXE_FLAG_TIMING) {
+    if (fs.timed) {
         float ms[EV_N] = {};
         for (int i = 1; i < EV_N; ++i) SXE_HIP(c, hipEventElapsedTime(&ms[i], fs.ev[i - 1], fs.ev[i]));
         sxe_timings &t = c->timings;
@@ -842,13 +850,13 @@ int sxe_rotation_system_span(sxe_ctx *c, uint64_t seed, uint32_t first_frame, ui
     if (n_frames == 0) return SXE_OK;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "rotation_system before update_drawables");
     if (!c->have_transforms) return fail(c, SXE_E_STATE, "model matrices were set directly; no transforms to rotate");
-    const bool timing = (c->cfg.flags & SXE_FLAG_TIMING) != 0;
     // the update belongs to the frame drawn next: its events live in that frame's slot
     if (c->frames_enqueued - c->frames_retired >= (uint64_t)kFrameSlots) {
         rc = retire_oldest(c);
         if (rc) return rc;
     }
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+    const bool timing = frame_is_timed(c, c->frames_enqueued);
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev_tr[0], c->stream));
     SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, n_frames, delta_ms, c->stream));
     if (timing) {
@@ -896,6 +904,7 @@ int sxe_draw(sxe_ctx *c, uint32_t image_index)
     }
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
     fs.image = image_index;
+    fs.timed = frame_is_timed(c, c->frames_enqueued);
     rc = enqueue_frame(c, fs, true);
     if (rc) return rc;
     c->frames_enqueued++;
@@ -920,6 +929,14 @@ int sxe_get_timing_totals(sxe_ctx *c, sxe_timings *sums, uint64_t *frames)
     if (!(c->cfg.flags & SXE_FLAG_TIMING)) return fail(c, SXE_E_STATE, "context was created without SXE_FLAG_TIMING");
     *sums = c->timing_totals;
     *frames = c->timed_frames;
+    return SXE_OK;
+}
+
+int sxe_set_timing_stride(sxe_ctx *c, uint32_t every)
+{
+    if (!c) return fail(c, SXE_E_INVALID, "null context");
+    if (every == 0) return fail(c, SXE_E_INVALID, "timing stride must be at least 1");
+    c->timing_stride = every;
     return SXE_OK;
 }
 

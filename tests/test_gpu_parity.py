@@ -246,8 +246,21 @@ def test_frames_in_flight(orc):
             d.sync()
             sums, frames = d.timing_totals()
             assert frames == 5 and sums["raster_shade_ms"] > 0.0
+            # events on a sample of the frames only: frames 6 and 9 of the ten drawn so far
+            d.set_timing_stride(3)
+            d.reset_timing_totals()
+            for f in range(5, 10):
+                d.rotation_system(3, f, 400.0)
+                orc.rotation_system(t, 3, f, 400.0)
+                d.draw(f % n_images)
+                refs.append(orc.render(s, orc.to_model(t), view, proj, w, h))
+            d.sync()
+            sums, frames = d.timing_totals()
+            assert frames == 2 and sums["raster_shade_ms"] > 0.0 and sums["transform_ms"] > 0.0
+            with pytest.raises(api.SxeError):
+                d.set_timing_stride(0)
             for img in range(n_images):
-                last = max(f for f in range(5) if f % n_images == img)
+                last = max(f for f in range(10) if f % n_images == img)
                 got = {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)}
                 assert_frames_equal(got, refs[last], what="image %d of %d holds frame %d" % (img, n_images, last))
         assert not np.array_equal(refs[3]["color"], refs[4]["color"])
