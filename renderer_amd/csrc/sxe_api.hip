@@ -104,7 +104,7 @@ struct sxe_ctx {
 
     // per-frame work buffers
     DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos;
-    DevBuf<uint4> bin_pos4, tile_launch;
+    DevBuf<uint4> bin_pos4, tile_launch, bin_start;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
     DevBuf<ClipItem> clip_list;
@@ -443,6 +443,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sc.blk_count = c->blk_count.p;
     sc.n_blocks = c->n_blocks;
     sc.tiles = sa.tiles;
+    sc.bin_start = c->bin_start.p;
     sc.tile_order = c->tile_counters.p + 9 * ntc;
     sc.n_tiles = nt;
     sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
@@ -461,6 +462,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.bin_pos = c->bin_pos.p;
     ba.bin_pos4 = c->bin_pos4.p;
     ba.tiles = sa.tiles;
+    ba.bin_start = reinterpret_cast<const uint32_t *>(c->bin_start.p);
     ba.late_fill = c->tile_counters.p + 8 * ntc;
     ba.tile_order = sc.tile_order;
     ba.tile_launch = c->tile_launch.p;
@@ -710,6 +712,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
     if ((e = c->tile_counters.reserve(10 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_launch.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile launch records)", e);
+    if ((e = c->bin_start.reserve(nt)) != hipSuccess) return bail("hipMalloc(bin class offsets)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
@@ -726,7 +729,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }

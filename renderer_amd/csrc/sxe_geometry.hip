@@ -687,6 +687,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
     __shared__ uint32_t s_part[16];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t last_tile = max(a.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
     if (blockIdx.x == 2) {
         // launch order of the tile workgroups: a counting sort by bin size class, fullest first,
         // so that the long-running tiles start early and the short ones fill the end of the launch
@@ -699,18 +700,20 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t i = (uint32_t)tid + 1024u * (uint32_t)k;
-            mine[k] = i < a.n_tiles ? order_class(tile_cost(a, i)) : 0u;
-            if (i < a.n_tiles) atomicAdd(&s_hist[mine[k]], 1u);
+            mine[k] = order_class(tile_cost(a, min(i, last_tile)));
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles) atomicAdd(&s_hist[mine[k]], 1u);
         for (uint32_t i = tid + 8192u; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u);
         __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0;
-            for (int k = kOrderClasses - 1; k >= 0; --k) {
-                const uint32_t h = s_hist[k];
-                s_hist[k] = run;
-                run += h;
-            }
+        if (wave == 0) {
+            // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
+            static_assert(kOrderClasses == 128, "two classes per lane of one wave");
+            const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
+            const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
+            s_hist[kOrderClasses - 1 - 2 * lane] = before;
+            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0;
         }
         __syncthreads();
 #pragma unroll
@@ -723,8 +726,18 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         return;
     }
     if (blockIdx.x == 1) {
+        // four counts per load, four loads in flight per thread
         uint32_t sum = 0;
-        for (uint32_t i = tid; i < a.n_blocks; i += 1024) sum += a.blk_count[i];
+        const uint32_t n4 = a.n_blocks / 4u;
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
+        for (uint32_t i = tid; i < n4; i += 4096) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (i + 1024u * k < n4) ? c4[i + 1024u * k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+        if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
         for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
         if (lane == 0) s_part[wave] = sum;
         __syncthreads();
@@ -735,13 +748,22 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         }
         return;
     }
+    // Sizes go through LDS so that both the loads of the counters and the stores of the offsets
+    // run along consecutive tiles in consecutive lanes, all of a thread's loads in flight at once.
+    __shared__ uint32_t s_size[8192];
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < a.n_tiles; base += 8192) {
-        const uint32_t i0 = base + 8u * (uint32_t)tid;
+        TileCtr mine[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + 1024u * k, last_tile)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_size[tid + 1024 * k] = (base + (uint32_t)tid + 1024u * k < a.n_tiles) ? bin_size(mine[k]) : 0u;
+        __syncthreads();
         uint32_t v[8], sum = 0;
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
-            v[k] = (i0 + k < a.n_tiles) ? bin_size(a, i0 + k) : 0u;
+            v[k] = s_size[8 * tid + k];
             sum += v[k];
         }
         const uint32_t incl = wave_inclusive_scan(sum, lane);
@@ -755,11 +777,18 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         }
         const uint32_t carry = s_carry;
         uint32_t run = carry + wbase + incl - sum;
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (i0 + k < a.n_tiles) a.tiles[i0 + k].off = run;
+            s_size[8 * tid + k] = run; // the tile's offset from here on
             run += v[k];
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + (uint32_t)tid + 1024u * k;
+            const uint32_t off = s_size[tid + 1024 * k], c0 = mine[k].cnt[0], c1 = mine[k].cnt[1], c2 = mine[k].cnt[2];
+            if (i < a.n_tiles) a.bin_start[i] = make_uint4(off, off + c0, off + c0 + c1, off + c0 + c1 + c2);
+        }
         if (tid == 0) s_carry = carry + tot;
         __syncthreads();
     }
@@ -782,66 +811,116 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // take one entry behind the reserved ones of each of those bins here.  A key is a kBinKey* value
 // or 4 * tile + size class.
 
-// First entry of size class `part` inside the tile's bin.
-__device__ inline uint32_t class_start(const TileCtr &t, uint32_t part)
+// Filing is split into its loads and its stores: the stores of one group of 64 slots must not sit
+// between the loads of the next (the compiler cannot tell that bins and tables do not overlap, so
+// it would wait for every group's round trip in turn).
+// Block of tiles a triangle's pixel box touches, from its raster record.
+__device__ inline bool block_from_record(const BinArgs &a, uint32_t rec, uint32_t &cols, uint32_t &rows, uint32_t &first)
 {
-    return t.off + (part > 0u ? t.cnt[0] : 0u) + (part > 1u ? t.cnt[1] : 0u) + (part > 2u ? t.cnt[2] : 0u);
+    const RastRec r = a.rast[rec];
+    int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+    if (r.x0 == kNoRaster ||
+        !pixel_box(unpack_tri(r, a.wide, rec), 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1))
+        return false;
+    cols = (uint32_t)(bx1 / kTile - bx0 / kTile) + 1u;
+    rows = (uint32_t)(by1 / kTile - by0 / kTile) + 1u;
+    first = (uint32_t)(by0 / kTile - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)(bx0 / kTile);
+    return true;
 }
 
-__device__ inline void bin_file(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p)
+struct BinLoads {
+    uint32_t start;   // single tile: first entry of the triangle's size class in that bin
+    uint32_t n_few;   // two to four tiles: how many
+    uint4 p4;         //   the positions k_setup reserved
+    uint32_t st[4];   //   and where the size class starts in each of those bins
+    uint32_t cols, rows, first; // block of tiles of a triangle that touches more than one
+    bool walk;        // more than four tiles: the triangle takes its entries in k_bin
+};
+
+__device__ inline BinLoads bin_gather(const BinArgs &a, bool valid, uint32_t rec, uint32_t key)
 {
-    if (valid && key < kBinKeyBlock) a.bins[class_start(a.tiles[key >> 2], key & 3u) + p] = rec;
-    if (a.debug & kDebugSkipLarge) return; // development: single-tile triangles only
-    uint32_t cols = 0, rows = 0, first = 0;
-    bool walk = false; // the triangle takes its entries itself, tile by tile
+    BinLoads g;
+    g.start = g.n_few = g.cols = g.rows = g.first = 0;
+    g.p4 = make_uint4(0, 0, 0, 0);
+    g.st[0] = g.st[1] = g.st[2] = g.st[3] = 0;
+    g.walk = false;
+    if (valid && key < kBinKeyBlock) g.start = a.bin_start[key];
+    if (a.debug & kDebugSkipLarge) return g; // development: single-tile triangles only
     if (valid && (key & 0xC0000000u) == kBinKeyBlock) {
-        cols = ((key >> 20) & 15u) + 1u;
-        rows = ((key >> 24) & 15u) + 1u;
-        first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
-        if (cols * rows <= 4u) {
+        g.cols = ((key >> 20) & 15u) + 1u;
+        g.rows = ((key >> 24) & 15u) + 1u;
+        g.first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
+        if (g.cols * g.rows <= 4u) {
             // up to four tiles: k_setup reserved the entries
             const uint32_t part = (key >> 28) & 3u;
-            const uint4 p4 = a.bin_pos4[rec];
-            const uint32_t given[4] = {p4.x, p4.y, p4.z, p4.w};
+            g.n_few = g.cols * g.rows;
+            g.p4 = a.bin_pos4[rec];
             uint32_t cx = 0, cy = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if ((uint32_t)j < cols * rows) {
-                    a.bins[class_start(a.tiles[first + cy * a.g.tiles_x + cx], part) + given[j]] = rec;
-                    if (++cx == cols) { cx = 0; ++cy; }
+                if ((uint32_t)j < g.n_few) {
+                    g.st[j] = a.bin_start[4u * (g.first + cy * a.g.tiles_x + cx) + part];
+                    if (++cx == g.cols) { cx = 0; ++cy; }
                 }
         } else {
-            walk = true;
+            g.walk = true;
         }
     }
-    if (valid && key == kBinKeyFromRecord) {
-        const RastRec r = a.rast[rec];
-        int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-        if (r.x0 != kNoRaster &&
-            pixel_box(unpack_tri(r, a.wide, rec), 0, (int32_t)a.g.width - 1, (int32_t)a.g.sy0, (int32_t)a.g.sy1 - 1, bx0, bx1, by0, by1)) {
-            cols = (uint32_t)(bx1 / kTile - bx0 / kTile) + 1u;
-            rows = (uint32_t)(by1 / kTile - by0 / kTile) + 1u;
-            first = (uint32_t)(by0 / kTile - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)(bx0 / kTile);
-            walk = true;
-        }
-    }
-    // The wave takes such triangles one at a time and spreads the tiles of each over its lanes:
-    // a lane walking a large block on its own would take one memory round trip per tile.
+    // blocks too large for a key
+    if (valid && key == kBinKeyFromRecord) g.walk = block_from_record(a, rec, g.cols, g.rows, g.first);
+    return g;
+}
+
+__device__ inline void bin_store(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p, const BinLoads &g)
+{
+    if (valid && key < kBinKeyBlock) a.bins[g.start + p] = rec;
+    const uint32_t given[4] = {g.p4.x, g.p4.y, g.p4.z, g.p4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((uint32_t)j < g.n_few) a.bins[g.st[j] + given[j]] = rec;
+}
+
+// Triangles over more than four tiles take one entry behind the reserved ones of each bin they
+// touch.  All (triangle, tile) pairs of the wave are dealt out over its lanes, 64 per round, so a
+// round costs one chain of memory round trips however many triangles are involved.  Every lane of
+// the wave must call this.
+__device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint32_t cols, uint32_t rows, uint32_t first)
+{
+    const unsigned long long todo = __ballot(walk);
+    if (!todo) return;
     const int lane = (int)(threadIdx.x & 63u);
-    unsigned long long todo = __ballot(walk);
-    while (todo) {
-        const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        todo &= todo - 1;
-        const uint32_t w_cols = (uint32_t)__builtin_amdgcn_readlane((int)cols, src), w_rows = (uint32_t)__builtin_amdgcn_readlane((int)rows, src);
-        const uint32_t w_first = (uint32_t)__builtin_amdgcn_readlane((int)first, src), w_rec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
-        for (uint32_t i = (uint32_t)lane; i < w_cols * w_rows; i += 64u) {
-            const uint32_t cy = i / w_cols, cx = i - cy * w_cols;
+    const uint32_t n_items = walk ? cols * rows : 0u;
+    uint32_t total = 0;
+    for (unsigned long long m = todo; m; m &= m - 1)
+        total += (uint32_t)__builtin_amdgcn_readlane((int)n_items, __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t owner = 0, local = 0, acc = 0;
+        for (unsigned long long m = todo; m; m &= m - 1) {
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            const uint32_t n_w = (uint32_t)__builtin_amdgcn_readlane((int)n_items, src);
+            if (i >= acc && i - acc < n_w) {
+                owner = (uint32_t)src;
+                local = i - acc;
+            }
+            acc += n_w;
+        }
+        const uint32_t w_cols = (uint32_t)__shfl((int)cols, (int)owner), w_first = (uint32_t)__shfl((int)first, (int)owner);
+        const uint32_t w_rec = (uint32_t)__shfl((int)rec, (int)owner);
+        if (i < total) {
+            const uint32_t cy = local / w_cols, cx = local - cy * w_cols;
             const uint32_t tl = w_first + cy * a.g.tiles_x + cx;
-            const TileCtr t = a.tiles[tl];
-            // behind the reserved entries of the bin
-            a.bins[t.off + bin_reserved(t) + atomicAdd(&a.late_fill[tl], 1u)] = w_rec;
+            a.bins[a.bin_start[4u * tl + 3u] + a.tiles[tl].cnt[3] + atomicAdd(&a.late_fill[tl], 1u)] = w_rec;
         }
     }
+}
+
+// A fan triangle of a clipped primitive: its tiles are derived from its record.
+__device__ inline void bin_fan(const BinArgs &a, bool valid, uint32_t rec)
+{
+    uint32_t cols = 0, rows = 0, first = 0;
+    const bool walk = valid && block_from_record(a, rec, cols, rows, first);
+    bin_walk(a, walk, rec, cols, rows, first);
 }
 
 // A wave files the survivors of one setup work item (their keys were written by k_setup); the
@@ -849,27 +928,46 @@ __device__ inline void bin_file(const BinArgs &a, bool valid, uint32_t rec, uint
 // are derived from their records.
 __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
 {
-    if (a.counters->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;
+    const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
+    const bool filing = blockIdx.x < seg_groups && seg < a.n_blocks;
+    // A wave's work is a chain of dependent loads.  Its first link asks for everything whose
+    // address is known: the overflow flag, the segment's count and, without waiting for the count,
+    // the first kEager * 64 keys and positions (values past the count are stale and ignored).
+    constexpr int kEager = 2;
+    uint32_t cnt_v = 0, keys[kSetupThreads / 64], pos[kSetupThreads / 64];
+#pragma unroll
+    for (int k = 0; k < kEager; ++k) {
+        keys[k] = kBinKeyNone;
+        pos[k] = 0;
+    }
+    if (filing) {
+        cnt_v = a.blk_count[seg];
+#pragma unroll
+        for (int k = 0; k < kEager; ++k) {
+            keys[k] = a.bin_keys[seg * kSetupThreads + 64u * k + (uint32_t)lane];
+            pos[k] = a.bin_pos[seg * kSetupThreads + 64u * k + (uint32_t)lane];
+        }
+    }
+    if (a.counters->overflow) return;
     // on the side: what the tile workgroups need to start, gathered into one record per launch position
     {
         const uint32_t i = blockIdx.x * kSetupThreads + (uint32_t)tid;
         if (i < a.g.n_tiles) {
             const uint32_t tile = a.tile_order[i];
-            const TileCtr t = a.tiles[tile];
-            a.tile_launch[i] = make_uint4(tile, t.off, bin_size(t), 0u);
+            a.tile_launch[i] = make_uint4(tile, a.bin_start[4u * tile], bin_size(a.tiles[tile]), 0u);
         }
     }
-    const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;
     if (blockIdx.x < seg_groups) {
-        const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
-        if (seg >= a.n_blocks) return;
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.blk_count[seg]);
+        if (!filing) return;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
         if (cnt == 0) return;
-        // all keys of the segment are requested before the first one is used
-        uint32_t keys[kSetupThreads / 64], pos[kSetupThreads / 64];
 #pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k) {
+        for (int k = 0; k < kEager; ++k)
+            if (64u * k + (uint32_t)lane >= cnt) keys[k] = kBinKeyNone;
+#pragma unroll
+        for (int k = kEager; k < kSetupThreads / 64; ++k) {
             const uint32_t i = 64u * k + (uint32_t)lane;
             keys[k] = i < cnt ? a.bin_keys[seg * kSetupThreads + i] : kBinKeyNone;
             pos[k] = i < cnt ? a.bin_pos[seg * kSetupThreads + i] : 0u;
@@ -878,17 +976,28 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
             if ((keys[0] ^ keys[1] ^ keys[2] ^ keys[3] ^ pos[0]) == 0x12345678u) a.bins[0] = 0;
             return;
         }
+        BinLoads g[kSetupThreads / 64];
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k) {
+            const uint32_t i = 64u * k + (uint32_t)lane;
+            g[k] = bin_gather(a, i < cnt, seg * kSetupThreads + i, keys[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kSetupThreads / 64; ++k) {
+            const uint32_t i = 64u * k + (uint32_t)lane;
+            bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k], g[k]);
+        }
 #pragma unroll
         for (int k = 0; k < kSetupThreads / 64; ++k)
             if (64u * k < cnt) {
                 const uint32_t i = 64u * k + (uint32_t)lane;
-                bin_file(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k]);
+                bin_walk(a, g[k].walk, seg * kSetupThreads + i, g[k].cols, g[k].rows, g[k].first);
             }
     } else {
         const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
         const uint32_t n_fan = a.counters->fan_records;
         if (first >= n_fan) return;
-        bin_file(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane, kBinKeyFromRecord, 0u);
+        bin_fan(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane);
     }
 }
 

@@ -138,15 +138,15 @@ struct ObjectArgs {
     FrameGeom g;
 };
 
-// Per-tile bookkeeping of a frame.  A tile's bin is the range [off, off + bin_size) of the bin
-// array, laid out by pixel-box size so that the lanes of a wave of the tile kernel walk boxes of
-// similar size: first the entries of size class 0, then class 1, 2, 3 (all reserved by k_setup,
-// cnt[] of them), then the `multi` entries that k_bin places itself (triangles touching more than
-// four tiles, fans of clipped triangles).  `off` is filled in by k_scan.
+// Per-tile bookkeeping of a frame.  A tile's bin is a range of bin_size entries of the bin array
+// (k_scan works out where it starts), laid out by pixel-box size so that the lanes of a wave of
+// the tile kernel walk boxes of similar size: first the entries of size class 0, then class 1, 2,
+// 3 (all reserved by k_setup, cnt[] of them), then the `multi` entries that k_bin places itself
+// (triangles touching more than four tiles, fans of clipped triangles).
 constexpr int kSizeClasses = 4;
 struct __attribute__((aligned(16))) TileCtr {
     uint32_t cnt[kSizeClasses];
-    uint32_t multi, off, pad0, pad1;
+    uint32_t multi, pad0, pad1, pad2;
 };
 __host__ __device__ inline uint32_t bin_reserved(const TileCtr &t) { return t.cnt[0] + t.cnt[1] + t.cnt[2] + t.cnt[3]; }
 __host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return bin_reserved(t) + t.multi; }
@@ -193,7 +193,8 @@ constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a cli
 struct ScanArgs {
     const uint32_t *blk_count;
     uint32_t n_blocks;
-    TileCtr *tiles;            // counts as k_setup and k_clip left them; `off` is written here
+    const TileCtr *tiles;      // counts as k_setup and k_clip left them
+    uint4 *bin_start;          // out, per tile: first bin entry of each of its four size classes
     uint32_t *tile_order;      // tiles in launch order: fullest bins first
     uint32_t n_tiles;
     uint32_t bin_capacity;
@@ -211,6 +212,7 @@ struct BinArgs {
     const uint32_t *bin_pos;
     const uint4 *bin_pos4;
     const TileCtr *tiles;
+    const uint32_t *bin_start; // [4 * tile + size class]: first bin entry of the class (from k_scan)
     uint32_t *late_fill;       // per tile: how many of its `multi` entries have been placed
     const uint32_t *tile_order;
     uint4 *tile_launch;        // per launch position: tile, bin offset, bin size, front entries
