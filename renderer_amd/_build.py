@@ -32,5 +32,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "..", "host")
+HOST_DEMO = os.path.join(HOST_DIR, "engine_demo")
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host side (include/sxe_drawer.hpp) and its frame-loop program: plain g++, no HIP headers."""
+    src = os.path.join(HOST_DIR, "engine_demo.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "sxe_drawer.hpp"), os.path.join(HERE, "..", "include", "sxe.h"), LIB]
+    if not force and os.path.exists(HOST_DEMO) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_DEMO) for d in deps):
+        return HOST_DEMO
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-Wextra", "-I", os.path.join(HERE, "..", "include"), src,
+           "-o", HOST_DEMO, "-L", HERE, "-lsxe_hip", "-Wl,-rpath,$ORIGIN/../renderer_amd", "-Wl,-rpath-link,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_DEMO
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_host(force=True, verbose=True)

@@ -134,3 +134,31 @@ def random_soup(rng, n, width, height, kinds=("tiny", "small", "medium", "large"
     snap = np.round((tris[..., :2] + 1) * 0.5 * np.array([width, height]) * 2) / 2
     tris[..., :2][m] = (snap[m] / np.array([width, height]) * 2 - 1).astype(np.float32)
     return tris
+
+
+def write_scene_file(path, scene, n_images=2, n_frames=1, rotate_deg=(0.0, 0.0, 0.0)):
+    """Scene file of host/engine_demo.cpp (format described there): reference-style drawables, one
+    mesh copy per object, textures referred to by path."""
+    import struct
+    w, h = scene.size
+    with open(path, "wb") as f:
+        f.write(b"SXES" + struct.pack("<I", 1))
+        f.write(struct.pack("<4I", w, h, n_images, n_frames))
+        f.write(np.asarray(rotate_deg, dtype="<f4").tobytes())
+        f.write(np.ascontiguousarray(scene.camera).tobytes())
+        f.write(struct.pack("<I", len(scene.textures)))
+        for k, t in enumerate(scene.textures):
+            name = ("textures/tex%03d.jpg" % k).encode()
+            f.write(struct.pack("<I", len(name)) + name)
+            f.write(struct.pack("<2I", t.shape[1], t.shape[0]))
+            f.write(np.ascontiguousarray(t, dtype=np.uint8).tobytes())
+        f.write(struct.pack("<I", len(scene.objects)))
+        for o, t in zip(scene.objects, scene.transforms):
+            m = scene.meshes[o["mesh"]]
+            v = scene.vertices[m["first_vertex"]:m["first_vertex"] + m["n_vertices"]]
+            i = scene.indices[m["first_index"]:m["first_index"] + m["n_indices"]]
+            f.write(struct.pack("<2I", len(v), len(i)))
+            f.write(np.ascontiguousarray(v).tobytes())
+            f.write(np.ascontiguousarray(i, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(t).tobytes())
+            f.write(struct.pack("<iI", int(o["texture"]), int(o["rendered"])))
