@@ -581,17 +581,13 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     }
 }
 
-constexpr uint32_t kBlocksPerGroup = 1; // work items one setup workgroup takes, one after the other
-
 // (six resident waves per SIMD matter more to this kernel than the last few registers)
-__global__ __launch_bounds__(kSetupThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_setup(SetupArgs a)
+__global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
 {
+    // one work item per workgroup (several in a loop measured slower, and a loop keeps per-thread
+    // addresses alive across it, which this kernel has no registers for)
     __shared__ SetupShared sh;
-    const uint32_t first = blockIdx.x * kBlocksPerGroup, last = min(first + kBlocksPerGroup, a.n_blocks);
-    for (uint32_t block = first; block < last; ++block) {
-        setup_block(a, block, sh);
-        __syncthreads(); // the next work item overwrites the shared arrays
-    }
+    setup_block(a, blockIdx.x, sh);
 }
 
 // One thread per queued triangle: Sutherland-Hodgman, then the fan of the clipped polygon goes to
@@ -1037,7 +1033,7 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_setup, dim3((a.n_blocks + kBlocksPerGroup - 1) / kBlocksPerGroup), dim3(kSetupThreads), 0, s, a);
+    hipLaunchKernelGGL(k_setup, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
