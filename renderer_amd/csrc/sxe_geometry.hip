@@ -807,9 +807,6 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 // take one entry behind the reserved ones of each of those bins here.  A key is a kBinKey* value
 // or 4 * tile + size class.
 
-// Filing is split into its loads and its stores: the stores of one group of 64 slots must not sit
-// between the loads of the next (the compiler cannot tell that bins and tables do not overlap, so
-// it would wait for every group's round trip in turn).
 // Block of tiles a triangle's pixel box touches, from its raster record.
 __device__ inline bool block_from_record(const BinArgs &a, uint32_t rec, uint32_t &cols, uint32_t &rows, uint32_t &first)
 {
@@ -824,56 +821,67 @@ __device__ inline bool block_from_record(const BinArgs &a, uint32_t rec, uint32_
     return true;
 }
 
+// The block of tiles a kBinKeyBlock key names.
+struct KeyBlock {
+    uint32_t cols, rows, first, part;
+};
+__device__ inline bool is_block_key(uint32_t key) { return (key & 0xC0000000u) == kBinKeyBlock; }
+__device__ inline KeyBlock decode_block(const BinArgs &a, uint32_t key)
+{
+    KeyBlock b;
+    b.cols = ((key >> 20) & 15u) + 1u;
+    b.rows = ((key >> 24) & 15u) + 1u;
+    b.first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
+    b.part = (key >> 28) & 3u;
+    return b;
+}
+
+// Filing is split into its loads and its stores: the stores of one group of 64 slots must not sit
+// between the loads of the next (the compiler cannot tell that bins and tables do not overlap, so
+// it would wait for every group's round trip in turn).  What the loads bring:
 struct BinLoads {
     uint32_t start;   // single tile: first entry of the triangle's size class in that bin
-    uint32_t n_few;   // two to four tiles: how many
-    uint4 p4;         //   the positions k_setup reserved
+    uint4 p4;         // two to four tiles: the positions k_setup reserved
     uint32_t st[4];   //   and where the size class starts in each of those bins
-    uint32_t cols, rows, first; // block of tiles of a triangle that touches more than one
-    bool walk;        // more than four tiles: the triangle takes its entries in k_bin
 };
 
 __device__ inline BinLoads bin_gather(const BinArgs &a, bool valid, uint32_t rec, uint32_t key)
 {
     BinLoads g;
-    g.start = g.n_few = g.cols = g.rows = g.first = 0;
+    g.start = 0;
     g.p4 = make_uint4(0, 0, 0, 0);
     g.st[0] = g.st[1] = g.st[2] = g.st[3] = 0;
-    g.walk = false;
     if (valid && key < kBinKeyBlock) g.start = a.bin_start[key];
     if (a.debug & kDebugSkipLarge) return g; // development: single-tile triangles only
-    if (valid && (key & 0xC0000000u) == kBinKeyBlock) {
-        g.cols = ((key >> 20) & 15u) + 1u;
-        g.rows = ((key >> 24) & 15u) + 1u;
-        g.first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
-        if (g.cols * g.rows <= 4u) {
-            // up to four tiles: k_setup reserved the entries
-            const uint32_t part = (key >> 28) & 3u;
-            g.n_few = g.cols * g.rows;
+    if (valid && is_block_key(key)) {
+        const KeyBlock b = decode_block(a, key);
+        if (b.cols * b.rows <= 4u) {
             g.p4 = a.bin_pos4[rec];
             uint32_t cx = 0, cy = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if ((uint32_t)j < g.n_few) {
-                    g.st[j] = a.bin_start[4u * (g.first + cy * a.g.tiles_x + cx) + part];
-                    if (++cx == g.cols) { cx = 0; ++cy; }
+                if ((uint32_t)j < b.cols * b.rows) {
+                    g.st[j] = a.bin_start[4u * (b.first + cy * a.g.tiles_x + cx) + b.part];
+                    if (++cx == b.cols) { cx = 0; ++cy; }
                 }
-        } else {
-            g.walk = true;
         }
     }
-    // blocks too large for a key
-    if (valid && key == kBinKeyFromRecord) g.walk = block_from_record(a, rec, g.cols, g.rows, g.first);
     return g;
 }
 
 __device__ inline void bin_store(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p, const BinLoads &g)
 {
     if (valid && key < kBinKeyBlock) a.bins[g.start + p] = rec;
+    if (a.debug & kDebugSkipLarge) return;
+    uint32_t n_few = 0;
+    if (valid && is_block_key(key)) {
+        const KeyBlock b = decode_block(a, key);
+        n_few = b.cols * b.rows <= 4u ? b.cols * b.rows : 0u;
+    }
     const uint32_t given[4] = {g.p4.x, g.p4.y, g.p4.z, g.p4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if ((uint32_t)j < g.n_few) a.bins[g.st[j] + given[j]] = rec;
+        if ((uint32_t)j < n_few) a.bins[g.st[j] + given[j]] = rec;
 }
 
 // Triangles over more than four tiles take one entry behind the reserved ones of each bin they
@@ -983,11 +991,21 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
             const uint32_t i = 64u * k + (uint32_t)lane;
             bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k], g[k]);
         }
+        if (a.debug & kDebugSkipLarge) return;
 #pragma unroll
         for (int k = 0; k < kSetupThreads / 64; ++k)
             if (64u * k < cnt) {
-                const uint32_t i = 64u * k + (uint32_t)lane;
-                bin_walk(a, g[k].walk, seg * kSetupThreads + i, g[k].cols, g[k].rows, g[k].first);
+                // more than four tiles (or a block too large for a key): entries are taken here
+                const uint32_t i = 64u * k + (uint32_t)lane, rec = seg * kSetupThreads + i;
+                uint32_t cols = 0, rows = 0, first = 0;
+                bool walk = false;
+                if (i < cnt && is_block_key(keys[k])) {
+                    const KeyBlock b = decode_block(a, keys[k]);
+                    cols = b.cols; rows = b.rows; first = b.first;
+                    walk = cols * rows > 4u;
+                }
+                if (i < cnt && keys[k] == kBinKeyFromRecord) walk = block_from_record(a, rec, cols, rows, first);
+                bin_walk(a, walk, rec, cols, rows, first);
             }
     } else {
         const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
