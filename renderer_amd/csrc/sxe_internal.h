@@ -17,8 +17,13 @@ constexpr float kGuard = 4.0f;     // guard band: x,y are clipped at +-kGuard*w 
 constexpr int kMaxFan = 7;         // a triangle clipped by six planes has at most 9 corners
 constexpr int kSmallBox = 8;       // bin entries whose pixel box holds <= this many pixels go to the
                                    // front of a tile's bin, the others to the back
-constexpr int kLaneBox = 64;       // largest pixel box one lane walks alone; larger ones take a whole wave
-constexpr unsigned long long kVisEmpty = ~0ull;
+constexpr int kLaneBox = 24;       // largest pixel box one lane walks alone; larger ones are shared by lanes,
+constexpr int kLaneBoxCrowd = 64;  // unless at least kCrowd lanes of the wave hold boxes up to this size
+constexpr int kCrowd = 24;
+// Untouched pixel of the tile's (depth bits << 32 | order) buffer: depth 1.0, order 0.  A fragment
+// at depth >= 1.0 can never be Less than the cleared 1.0, and its key is never below this value, so
+// the 64-bit minimum rejects it without a comparison of its own.
+constexpr unsigned long long kVisEmpty = 0x3F800000ull << 32;
 constexpr int32_t kNoRaster = INT32_MIN; // RastRec.x0 of a slot that holds no triangle to rasterise
 // development-only switches carried in sxe_config.flags (timing experiments; outputs are wrong)
 constexpr uint32_t kDebugSkipRaster = 1u << 30, kDebugSkipResolve = 1u << 31;

@@ -85,7 +85,21 @@ struct WideEntry {                // a queued triangle: corners, depth plane, su
     int32_t x0, y0, x1, y1, x2, y2;
     float z0, dz1, dz2;
     uint32_t order;
+    uint32_t box;                 // its pixel box inside the tile, see pack_box
 };
+// Boxes of the queue up to this many pixels (narrow triangles only) are walked by groups of 16
+// lanes, sixteen triangles at a time per workgroup; larger ones by all 256 threads together.
+constexpr uint32_t kGroupBox = 128;
+constexpr uint32_t kBoxNarrow = 1u << 20;
+__device__ inline uint32_t pack_box(int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, int32_t tpx, int32_t tpy, bool is_narrow)
+{
+    return (uint32_t)(bx0 - tpx) | ((uint32_t)(by0 - tpy) << 5) | ((uint32_t)(bx1 - bx0) << 10) | ((uint32_t)(by1 - by0) << 15) |
+           (is_narrow ? kBoxNarrow : 0u);
+}
+__device__ inline bool box_for_group(uint32_t box)
+{
+    return (box & kBoxNarrow) && (((box >> 10) & 31u) + 1u) * (((box >> 15) & 31u) + 1u) <= kGroupBox;
+}
 constexpr int kTexCache = 64;     // texture descriptors kept in LDS
 constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
 constexpr int kEntriesPerLane = 2; // bin entries a lane fetches together
@@ -149,17 +163,16 @@ __device__ inline float clamp_depth(float z)
     return z;
 }
 
+// z is not negative (clamp_depth).  No read first: the LDS read would have to come back before the
+// lane can go on, the atomic does not.
 __device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint32_t order)
 {
-    if (z < 1.0f) { // a depth of 1.0 can never be Less than the cleared 1.0
-        const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | order;
-        // no read first: the LDS read would have to come back before the lane can go on, the
-        // atomic does not
-        atomicMin(&vis[pix], key);
-    }
+    atomicMin(&vis[pix], ((unsigned long long)__float_as_uint(z) << 32) | order);
 }
 
-// One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions.
+// One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions, row
+// by row; the step to the next pixel is chosen between "one to the right" and "first of the next
+// row" by selects, so the loop body has no branch but the coverage test.
 __device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
                                    int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
 {
@@ -167,25 +180,28 @@ __device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const 
     const EdgeStart e = edge_start(t, bx0, by0);
     const int32_t b1 = e.b1, b2 = e.b2;
     const float rA = 1.0f / (float)(mul_narrow(e.ex2, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, e.ey2));
-    int32_t R0 = e.R0, R1 = e.R1, R2 = e.R2;
+    const int32_t last = bx1 - bx0; // column index of a row's last pixel
     const int32_t ax0 = -256 * e.ey0, ax1 = -256 * e.ey1, ax2 = -256 * e.ey2; // one pixel to the right
-    const int32_t ay0 = 256 * e.ex0, ay1 = 256 * e.ex1, ay2 = 256 * e.ex2;    // one pixel down
-    int32_t E0 = R0, E1 = R1, E2 = R2;
-    int32_t i = bx0, j = by0;
-    const int32_t cnt = mul_narrow(bx1 - bx0 + 1, by1 - by0 + 1);
+    // from the last pixel of a row to the first of the next: one down, `last` to the left
+    const int32_t aw0 = 256 * e.ex0 - mul_narrow(ax0, last), aw1 = 256 * e.ex1 - mul_narrow(ax1, last),
+                  aw2 = 256 * e.ex2 - mul_narrow(ax2, last);
+    int32_t E0 = e.R0, E1 = e.R1, E2 = e.R2;
+    int32_t col = 0;
+    int32_t pix = (by0 - tpy) * kTile + (bx0 - tpx);
+    const int32_t pix_wrap = kTile - last;
+    const int32_t cnt = mul_narrow(last + 1, by1 - by0 + 1);
     for (int32_t k = 0; k < cnt; ++k) {
         if ((E0 | E1 | E2) >= 0) {
             const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
             const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-            depth_min(vis, (j - tpy) * kTile + (i - tpx), z, r.order);
+            depth_min(vis, pix, z, r.order);
         }
-        E0 += ax0; E1 += ax1; E2 += ax2;
-        if (++i > bx1) {
-            i = bx0;
-            ++j;
-            R0 += ay0; R1 += ay1; R2 += ay2;
-            E0 = R0; E1 = R1; E2 = R2;
-        }
+        const bool wrap = col == last;
+        E0 += wrap ? aw0 : ax0;
+        E1 += wrap ? aw1 : ax1;
+        E2 += wrap ? aw2 : ax2;
+        pix += wrap ? pix_wrap : 1;
+        col = wrap ? 0 : col + 1;
     }
 }
 
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     __shared__ TexDev s_tex[kTexCache];
     __shared__ WideEntry s_wq[kWideQueue];
     __shared__ uint32_t s_nwq, s_ncov;
+    __shared__ uint32_t s_magic[33]; // idx / w == (idx * s_magic[w]) >> 16 for idx < 1024, w <= 32
     __shared__ uint16_t s_cov[kTilePixels]; // tile-local indices of the covered pixels
     // the frame's counters are final by now: report them to the host without a copy command
     if (blockIdx.x == 0 && a.host_counters && threadIdx.x < sizeof(FrameCounters) / 4)
@@ -317,6 +334,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     s_dec[tid] = c_srgb_decode[tid];
     if (tid < kTexCache && (uint32_t)tid < a.n_textures) s_tex[tid] = a.textures[tid];
     if (tid == 0) { s_nwq = 0; s_ncov = 0; }
+    if (tid >= 1 && tid <= 32) s_magic[tid] = (65536u + (uint32_t)tid - 1u) / (uint32_t)tid;
     __syncthreads();
     SXE_STAMP(1);
 
@@ -352,16 +370,26 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const RastRec r = recs[k];
             Tri t = {0, 0, 0, 0, 0, 0};
             int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            bool nonempty = false, is_narrow = false;
+            int32_t box_px = 0;
             if (valid) {
-                const uint32_t slot = slots[k];
-                t = unpack_tri(r, a.wide, slot);
-                const bool nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
-                const bool alone = nonempty && (bx1 - bx0 + 1) * (by1 - by0 + 1) <= kLaneBox && narrow(t);
+                t = unpack_tri(r, a.wide, slots[k]);
+                nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
+                is_narrow = narrow(t);
+                box_px = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+            }
+            // Boxes of 25 to 64 pixels: when a wave holds many of them its lanes are evenly loaded
+            // and walking them lane by lane is the cheapest way; a few among small boxes would keep
+            // the whole wave waiting, so they go to the queue that lane groups share.
+            const bool middling = nonempty && is_narrow && box_px > kLaneBox && box_px <= kLaneBoxCrowd;
+            const int32_t lane_box = __popcll(__ballot(middling)) >= kCrowd ? kLaneBoxCrowd : kLaneBox;
+            if (valid) {
+                const bool alone = nonempty && box_px <= lane_box && is_narrow;
                 wide_box = nonempty && !alone && !(a.debug & kDebugSkipLarge);
                 if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, bx0, bx1, by0, by1, tpx, tpy);
                 if (a.debug & kDebugSkipAtomic) { // development census of the two raster paths
                     FrameCounters *ctr = const_cast<FrameCounters *>(a.counters);
-                    const uint32_t box = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+                    const uint32_t box = (uint32_t)box_px;
                     if (wide_box) { atomicAdd(&ctr->pad[0], 1u); atomicAdd(&ctr->pad[1], box); }
                     if (alone) atomicAdd(&ctr->pad[2], box);
                 }
@@ -373,6 +401,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
                         WideEntry q;
                         q.x0 = t.x0; q.y0 = t.y0; q.x1 = t.x1; q.y1 = t.y1; q.x2 = t.x2; q.y2 = t.y2;
                         q.z0 = r.z0; q.dz1 = r.dz1; q.dz2 = r.dz2; q.order = r.order;
+                        q.box = pack_box(bx0, bx1, by0, by1, tpx, tpy, is_narrow);
                         s_wq[qi] = q;
                         wide_box = false;
                     }
@@ -396,11 +425,39 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
     SXE_STAMP(3);
     {
-        // every wave loads the queued triangles and takes every fourth 64-pixel step of each
         const uint32_t nq = min(s_nwq, (uint32_t)kWideQueue);
+        // Middle-sized boxes: a group of 16 lanes per triangle, 16 pixels per step.  Every lane of
+        // the group reads the same queue entry and prepares the edge functions for itself.
+        const uint32_t gl = (uint32_t)lane & 15u, grp = (uint32_t)wave * 4u + ((uint32_t)lane >> 4);
+        for (uint32_t e = grp; e < nq; e += 16u) {
+            const WideEntry q = s_wq[e];
+            if (!box_for_group(q.box)) continue;
+            const int32_t bx0 = tpx + (int32_t)(q.box & 31u), by0 = tpy + (int32_t)((q.box >> 5) & 31u);
+            const uint32_t bw = ((q.box >> 10) & 31u) + 1u, cnt = bw * (((q.box >> 15) & 31u) + 1u);
+            const Tri t = {q.x0, q.y0, q.x1, q.y1, q.x2, q.y2};
+            const EdgeStart es = edge_start(t, bx0, by0);
+            const float rA = 1.0f / (float)(mul_narrow(es.ex2, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, es.ey2));
+            const int32_t ax0 = -256 * es.ey0, ax1 = -256 * es.ey1, ax2 = -256 * es.ey2; // one pixel to the right
+            const int32_t ay0 = 256 * es.ex0, ay1 = 256 * es.ex1, ay2 = 256 * es.ex2;    // one pixel down
+            const uint32_t magic = s_magic[bw];
+            for (uint32_t idx = gl; idx < cnt; idx += 16u) {
+                const uint32_t row = __umul24(idx, magic) >> 16;
+                const int32_t di = (int32_t)(idx - __umul24(row, bw)), dj = (int32_t)row;
+                // steps are below 2^22 and pixel offsets below 2^6: 24-bit multiplies are exact
+                const int32_t E0 = es.R0 + mul_narrow(ax0, di) + mul_narrow(ay0, dj);
+                const int32_t E1 = es.R1 + mul_narrow(ax1, di) + mul_narrow(ay1, dj);
+                const int32_t E2 = es.R2 + mul_narrow(ax2, di) + mul_narrow(ay2, dj);
+                if ((E0 | E1 | E2) >= 0) {
+                    const float l1 = (float)(E1 + es.b1) * rA, l2 = (float)(E2 + es.b2) * rA;
+                    const float z = clamp_depth((q.z0 + l1 * q.dz1) + l2 * q.dz2);
+                    depth_min(vis, (by0 + dj - tpy) * kTile + (bx0 + di - tpx), z, q.order);
+                }
+            }
+        }
+        // The rest: every wave loads the queued triangles and takes every fourth 64-pixel step of each
         for (uint32_t base = 0; base < nq; base += 64u) {
             const uint32_t e = base + (uint32_t)lane;
-            const bool valid = e < nq;
+            const bool valid = e < nq && !box_for_group(s_wq[min(e, (uint32_t)kWideQueue - 1u)].box);
             RastRec r;
             r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
             Tri t = {0, 0, 0, 0, 0, 0};
