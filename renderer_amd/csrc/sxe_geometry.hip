@@ -560,11 +560,20 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         a.bin_pos[slot0 + tid] = sh.pos[tid];
     }
     {
+        // (total <= 256: at most two and three 16-byte pieces per thread)
         uint4 *dst = reinterpret_cast<uint4 *>(a.rast + slot0);
-        for (uint32_t c = (uint32_t)tid; c < 2u * total; c += kSetupThreads) dst[c] = sh.stage[c];
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint32_t c = (uint32_t)tid + k * kSetupThreads;
+            if (c < 2u * total) dst[c] = sh.stage[c];
+        }
         dst = reinterpret_cast<uint4 *>(a.shade + slot0);
         const uint4 *ss = sh.stage + 2 * kSetupThreads;
-        for (uint32_t c = (uint32_t)tid; c < 3u * total; c += kSetupThreads) dst[c] = ss[c];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const uint32_t c = (uint32_t)tid + k * kSetupThreads;
+            if (c < 3u * total) dst[c] = ss[c];
+        }
     }
 
     // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
