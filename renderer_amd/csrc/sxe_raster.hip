@@ -80,7 +80,7 @@ static hipError_t ensure_tables()
     return hipSuccess;
 }
 
-constexpr int kWideQueue = 96;    // wide-box entries of one tile that all four waves share
+constexpr int kWideQueue = 72;    // wide-box entries of one tile that all four waves share
 struct WideEntry {                // a queued triangle: corners, depth plane, submission order
     int32_t x0, y0, x1, y1, x2, y2;
     float z0, dz1, dz2;
@@ -304,8 +304,8 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
     }
 }
 
-// (seven resident workgroups per compute unit: 72 registers and under 23 KB of LDS; measured 3 %
-// faster than six, while eight would need spills)
+// (seven resident workgroups per compute unit: 72 registers and at most 22 KB of LDS, which is
+// handed out in 1 KB pieces; eight would need spills)
 template <bool COVERAGE>
 __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_raster_shade(RasterArgs a)
 {
