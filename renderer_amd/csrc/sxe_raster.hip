@@ -80,7 +80,7 @@ static hipError_t ensure_tables()
     return hipSuccess;
 }
 
-constexpr int kWideQueue = 72;    // wide-box entries of one tile that all four waves share
+constexpr int kWideQueue = 120;   // wide-box entries of one tile that all four waves share
 struct WideEntry {                // a queued triangle: corners, depth plane, submission order
     int32_t x0, y0, x1, y1, x2, y2;
     float z0, dz1, dz2;
@@ -313,10 +313,12 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     __shared__ __attribute__((aligned(16))) uint32_t s_enc[kEncPadded];
     __shared__ float s_dec[256];
     __shared__ TexDev s_tex[kTexCache];
-    __shared__ WideEntry s_wq[kWideQueue];
+    // the queue of large boxes and the list of covered pixels are never in use at the same time
+    __shared__ union { WideEntry wq[kWideQueue]; uint16_t cov[kTilePixels]; } s_overlay;
+    WideEntry *s_wq = s_overlay.wq;
+    uint16_t *s_cov = s_overlay.cov; // tile-local indices of the covered pixels
     __shared__ uint32_t s_nwq, s_ncov;
     __shared__ uint32_t s_magic[33]; // idx / w == (idx * s_magic[w]) >> 16 for idx < 1024, w <= 32
-    __shared__ uint16_t s_cov[kTilePixels]; // tile-local indices of the covered pixels
     // the frame's counters are final by now: report them to the host without a copy command
     if (blockIdx.x == 0 && a.host_counters && threadIdx.x < sizeof(FrameCounters) / 4)
         reinterpret_cast<uint32_t *>(a.host_counters)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.counters)[threadIdx.x];
