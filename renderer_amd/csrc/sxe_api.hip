@@ -103,7 +103,7 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos;
+    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos, walk_list;
     DevBuf<uint4> bin_pos4, tile_launch, bin_start;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
@@ -198,6 +198,7 @@ hipError_t reserve_records(sxe_ctx *c)
     if ((e = c->rast.reserve(n)) != hipSuccess) return e;
     if ((e = c->wide.reserve(n)) != hipSuccess) return e;
     if ((e = c->shade.reserve(n)) != hipSuccess) return e;
+    if ((e = c->walk_list.reserve(n)) != hipSuccess) return e;
     if ((e = c->bin_keys.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if ((e = c->bin_pos.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if ((e = c->bin_pos4.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
@@ -433,6 +434,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sa.color = c->color.p;
     sa.fan_capacity = (uint32_t)c->fan_capacity;
     sa.clip_list = c->clip_list.p;
+    sa.walk_list = c->walk_list.p;
     sa.bin_keys = c->bin_keys.p;
     sa.counters = c->counters.p;
     SXE_HIP(c, launch_setup(sa, s));
@@ -455,7 +457,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.g = c->g;
     ba.blk_count = c->blk_count.p;
     ba.n_blocks = c->n_blocks;
-    ba.fan_blocks = (uint32_t)((c->fan_capacity + kSetupThreads - 1) / kSetupThreads);
+    ba.walk_blocks = 256; // 1024 waves share the list of late entries, however long it is
     ba.rast = c->rast.p;
     ba.wide = c->wide.p;
     ba.bin_keys = c->bin_keys.p;
@@ -468,6 +470,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     ba.tile_launch = c->tile_launch.p;
     ba.bins = c->bins.p;
     ba.counters = c->counters.p;
+    ba.walk_list = c->walk_list.p;
     // the binning switches leave the bins unusable: only honoured when the tile kernel skips them
     ba.debug = (c->cfg.flags & kDebugSkipRaster) ? (c->cfg.flags & kDebugMask) : 0u;
     SXE_HIP(c, launch_bin(ba, s));
@@ -729,7 +732,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->walk_list.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }

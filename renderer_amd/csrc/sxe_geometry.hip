@@ -510,7 +510,21 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
             if (++cx > cols_m1) { cx = 0; ++cy; }
         }
     }
-    if (state == FAST && !single && !few) count_box(a, st);
+    {
+        // Triangles over more than four tiles are only counted here; their slots go on a list that
+        // k_bin spreads evenly over waves of its own (one list position per wave of this kernel
+        // would leave a wave full of such triangles with all of their entries to file).
+        const bool walker = state == FAST && !single && !few;
+        if (walker) count_box(a, st);
+        const unsigned long long wm = __ballot(walker);
+        if (wm) {
+            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&a.counters->walk_count, (uint32_t)__popcll(wm));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (walker) a.walk_list[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = slot;
+        }
+    }
 
     // The records go to memory through LDS: a lane storing its own 32- and 48-byte records would
     // send the L2 one 16-byte request per lane and instruction; laid out in slot order first, the
@@ -651,6 +665,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
         write_records(a, rec, slot, s2, prim, inst.texture, u, v, cr, cg, cb);
         count_box(a, s2);
+        a.walk_list[atomicAdd(&a.counters->walk_count, 1u)] = rec; // (clipping is rare: one atomic per fan triangle)
     }
 }
 
@@ -928,17 +943,10 @@ __device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint3
     }
 }
 
-// A fan triangle of a clipped primitive: its tiles are derived from its record.
-__device__ inline void bin_fan(const BinArgs &a, bool valid, uint32_t rec)
-{
-    uint32_t cols = 0, rows = 0, first = 0;
-    const bool walk = valid && block_from_record(a, rec, cols, rows, first);
-    bin_walk(a, walk, rec, cols, rows, first);
-}
-
 // A wave files the survivors of one setup work item (their keys were written by k_setup); the
-// workgroups past the last work item take the fan triangles of clipped primitives, whose tiles
-// are derived from their records.
+// workgroups past the last work item take the listed triangles that span more than four tiles and
+// the fan triangles of clipped primitives.
+constexpr uint32_t kWalkChunk = 16;
 __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1000,27 +1008,32 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
             const uint32_t i = 64u * k + (uint32_t)lane;
             bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k], g[k]);
         }
-        if (a.debug & kDebugSkipLarge) return;
-#pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k)
-            if (64u * k < cnt) {
-                // more than four tiles (or a block too large for a key): entries are taken here
-                const uint32_t i = 64u * k + (uint32_t)lane, rec = seg * kSetupThreads + i;
-                uint32_t cols = 0, rows = 0, first = 0;
-                bool walk = false;
-                if (i < cnt && is_block_key(keys[k])) {
-                    const KeyBlock b = decode_block(a, keys[k]);
-                    cols = b.cols; rows = b.rows; first = b.first;
-                    walk = cols * rows > 4u;
-                }
-                if (i < cnt && keys[k] == kBinKeyFromRecord) walk = block_from_record(a, rec, cols, rows, first);
-                bin_walk(a, walk, rec, cols, rows, first);
-            }
     } else {
-        const uint32_t first = (blockIdx.x - seg_groups) * kSetupThreads + 64u * (uint32_t)wave;
-        const uint32_t n_fan = a.counters->fan_records;
-        if (first >= n_fan) return;
-        bin_fan(a, first + lane < n_fan, a.n_blocks * kSetupThreads + first + lane);
+        // Late entries.  The listed triangles are dealt out sixteen to a wave and round, so that
+        // the dependent memory round trips of a crowd of them (a mesh close to the camera) are
+        // spread over many waves instead of queueing up in one.
+        if (a.debug & (kDebugSkipLarge | kDebugSkipAtomic)) return; // development: without the late entries
+        const uint32_t n_walk = a.counters->walk_count;
+        const uint32_t n_slots = a.n_blocks * kSetupThreads;
+        const uint32_t wave_id = (blockIdx.x - seg_groups) * 4u + (uint32_t)wave;
+        for (uint32_t base = wave_id * kWalkChunk; base < n_walk; base += a.walk_blocks * 4u * kWalkChunk) {
+            const bool mine = (uint32_t)lane < kWalkChunk && base + (uint32_t)lane < n_walk;
+            uint32_t rec = 0, key = kBinKeyFromRecord;
+            if (mine) {
+                rec = a.walk_list[base + (uint32_t)lane];
+                if (rec < n_slots) key = a.bin_keys[rec]; // (fan triangles have no key)
+            }
+            uint32_t cols = 0, rows = 0, first = 0;
+            bool walk = false;
+            if (mine && is_block_key(key)) {
+                const KeyBlock b = decode_block(a, key);
+                cols = b.cols; rows = b.rows; first = b.first;
+                walk = true;
+            } else if (mine) {
+                walk = block_from_record(a, rec, cols, rows, first);
+            }
+            bin_walk(a, walk, rec, cols, rows, first);
+        }
     }
 }
 
@@ -1081,7 +1094,7 @@ hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 hipError_t launch_bin(const BinArgs &a, hipStream_t s)
 {
     // (enough workgroups for the per-tile launch records even when there is nothing to file)
-    const uint32_t filing = (a.n_blocks + 3u) / 4u + a.fan_blocks, listing = (a.g.n_tiles + kSetupThreads - 1u) / kSetupThreads;
+    const uint32_t filing = (a.n_blocks + 3u) / 4u + a.walk_blocks, listing = (a.g.n_tiles + kSetupThreads - 1u) / kSetupThreads;
     const uint32_t groups = filing > listing ? filing : listing;
     if (groups == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bin, dim3(groups), dim3(kSetupThreads), 0, s, a);

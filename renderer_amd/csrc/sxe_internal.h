@@ -112,7 +112,8 @@ struct FrameCounters {
     uint32_t fan_records;   // fan triangles of clipped primitives
     uint32_t overflow;      // kOverflow* bits
     uint32_t clip_count;    // triangles handed to the clip kernel
-    uint32_t pad[11];       // development counters (box census, phase clocks)
+    uint32_t walk_count;    // triangles that take their bin entries in k_bin (entries of walk_list)
+    uint32_t pad[10];       // development counters (box census)
 };
 
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
@@ -185,6 +186,7 @@ struct SetupArgs {
     uint32_t fan_capacity;     // records available past slot 256 * n_blocks; also the clip list's length
     ClipItem *clip_list;
     uint32_t *bin_keys;        // per order slot: where k_bin files the triangle (kBinKey*)
+    uint32_t *walk_list;       // slots of the triangles over more than four tiles and of the fan triangles
     FrameCounters *counters;
 };
 
@@ -210,10 +212,11 @@ struct BinArgs {
     FrameGeom g;
     const uint32_t *blk_count;
     uint32_t n_blocks;
-    uint32_t fan_blocks;       // workgroups launched for the fan region
+    uint32_t walk_blocks;      // workgroups launched for the late entries (walk_list)
     const RastRec *rast;
     const WideRec *wide;
     const uint32_t *bin_keys;
+    const uint32_t *walk_list; // slots whose triangles take their entries here, counters->walk_count of them
     const uint32_t *bin_pos;
     const uint4 *bin_pos4;
     const TileCtr *tiles;

@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from renderer_amd import api, scenes
-s = scenes.config_scene(3)
+s = scenes.config_scene(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 w, h = s.size
 with api.HipDrawer(w, h) as d:
     d.update_scene(s); d.update_camera(s.camera)
