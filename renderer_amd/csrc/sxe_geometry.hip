@@ -699,53 +699,51 @@ __device__ inline uint32_t tile_cost(const ScanArgs &a, uint32_t i)
     return (t.cnt[0] + t.cnt[1] + 2u * t.cnt[2] + 8u * t.cnt[3] + 100u * t.multi) >> 2;
 }
 
-// Workgroup 0: bin size of every tile and their exclusive scan (eight tiles per thread and round).
-// Workgroup 1: total number of surviving triangles.
-// Workgroup 2: launch order of the tiles.
+// Tiles are handled in chunks of 8192 (eight per thread).  With C chunks the grid is
+//   workgroup 0:        total number of surviving triangles;
+//   workgroups 1..C:    bin sizes of a chunk's tiles, their exclusive scan and the per-class offsets;
+//   workgroups C+1..2C: launch order of a chunk's tiles.
+// A workgroup works out what the chunks before its own contribute by itself (their sizes, their
+// class histogram), which costs one more coalesced pass over the counters and no synchronisation
+// between workgroups.
+constexpr uint32_t kScanChunk = 8192;
+
+__device__ inline uint32_t block_sum(uint32_t v, uint32_t *s_part, int lane, int wave)
+{
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads(); // s_part may still be read from an earlier call
+    if (lane == 0) s_part[wave] = v;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) tot += s_part[w];
+    return tot;
+}
+
+// counter[cls] += 1 for every lane with `on`; returns the value before the lane's own increment.
+// Lanes that share the class of the first such lane (runs of empty or alike tiles are common) go
+// together in one atomic: LDS atomics of one instruction on one address are done one by one.
+__device__ inline uint32_t class_take(uint32_t *counter, uint32_t cls, bool on, int lane)
+{
+    const unsigned long long active = __ballot(on);
+    if (!active) return 0;
+    const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)active) - 1);
+    const uint32_t lead_cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, leader);
+    const bool grouped = on && cls == lead_cls;
+    const unsigned long long group = __ballot(grouped);
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(&counter[cls], (uint32_t)__popcll(group));
+    at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader) + (uint32_t)__popcll(group & ((1ull << lane) - 1ull));
+    if (on && !grouped) at = atomicAdd(&counter[cls], 1u);
+    return at;
+}
+
 __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 {
     __shared__ uint32_t s_part[16];
-    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t last_tile = max(a.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
-    if (blockIdx.x == 2) {
-        // launch order of the tile workgroups: a counting sort by bin size class, fullest first,
-        // so that the long-running tiles start early and the short ones fill the end of the launch
-        __shared__ uint32_t s_hist[kOrderClasses];
-        if (tid < kOrderClasses) s_hist[tid] = 0;
-        __syncthreads();
-        // (a thread keeps the classes of its first eight tiles: frames up to 8192 tiles read the
-        // counters once)
-        uint32_t mine[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = (uint32_t)tid + 1024u * (uint32_t)k;
-            mine[k] = order_class(tile_cost(a, min(i, last_tile)));
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if ((uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles) atomicAdd(&s_hist[mine[k]], 1u);
-        for (uint32_t i = tid + 8192u; i < a.n_tiles; i += 1024) atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u);
-        __syncthreads();
-        if (wave == 0) {
-            // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
-            static_assert(kOrderClasses == 128, "two classes per lane of one wave");
-            const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
-            const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
-            s_hist[kOrderClasses - 1 - 2 * lane] = before;
-            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = (uint32_t)tid + 1024u * (uint32_t)k;
-            if (i < a.n_tiles) a.tile_order[atomicAdd(&s_hist[mine[k]], 1u)] = i;
-        }
-        for (uint32_t i = tid + 8192u; i < a.n_tiles; i += 1024)
-            a.tile_order[atomicAdd(&s_hist[order_class(tile_cost(a, i))], 1u)] = i;
-        return;
-    }
-    if (blockIdx.x == 1) {
+    const uint32_t chunks = max((a.n_tiles + kScanChunk - 1u) / kScanChunk, 1u);
+    if (blockIdx.x == 0) {
         // four counts per load, four loads in flight per thread
         uint32_t sum = 0;
         const uint32_t n4 = a.n_blocks / 4u;
@@ -758,62 +756,107 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
             for (int k = 0; k < 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
         if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
-        for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
-        if (lane == 0) s_part[wave] = sum;
+        const uint32_t tot = block_sum(sum, s_part, lane, wave);
+        if (tid == 0) a.counters->total_records = tot;
+        return;
+    }
+    if (blockIdx.x > chunks) {
+        // launch order of the tile workgroups: a counting sort by estimated cost, dearest first, so
+        // that the long-running tiles start early and the short ones fill the end of the launch
+        const uint32_t chunk = blockIdx.x - chunks - 1u, base = chunk * kScanChunk;
+        __shared__ uint32_t s_hist[kOrderClasses], s_before[kOrderClasses];
+        if (tid < kOrderClasses) s_hist[tid] = s_before[tid] = 0;
         __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < 16; ++w) tot += s_part[w];
-            a.counters->total_records = tot;
+        uint32_t mine[8]; // classes of this chunk's tiles: the counters are read once
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k] = order_class(tile_cost(a, min(base + (uint32_t)tid + 1024u * (uint32_t)k, last_tile)));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) class_take(s_hist, mine[k], base + (uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles, lane);
+        // the other chunks: every tile counts for the class sizes, the earlier ones also for this
+        // chunk's place inside each class
+        for (uint32_t other = 0; other < chunks; ++other)
+            if (other != chunk) {
+                uint32_t cls[8]; // (all eight loads in flight together)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    cls[k] = order_class(tile_cost(a, min(other * kScanChunk + (uint32_t)tid + 1024u * (uint32_t)k, last_tile)));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool on = other * kScanChunk + (uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles;
+                    class_take(s_hist, cls[k], on, lane);
+                    if (other < chunk) class_take(s_before, cls[k], on, lane);
+                }
+            }
+        __syncthreads();
+        if (wave == 0) {
+            // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
+            static_assert(kOrderClasses == 128, "two classes per lane of one wave");
+            const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
+            const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
+            s_hist[kOrderClasses - 1 - 2 * lane] = before + s_before[kOrderClasses - 1 - 2 * lane];
+            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0 + s_before[kOrderClasses - 2 - 2 * lane];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + (uint32_t)tid + 1024u * (uint32_t)k;
+            const uint32_t at = class_take(s_hist, mine[k], i < a.n_tiles, lane);
+            if (i < a.n_tiles) a.tile_order[at] = i;
         }
         return;
     }
-    // Sizes go through LDS so that both the loads of the counters and the stores of the offsets
-    // run along consecutive tiles in consecutive lanes, all of a thread's loads in flight at once.
-    __shared__ uint32_t s_size[8192];
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < a.n_tiles; base += 8192) {
-        TileCtr mine[8];
+    // Bin offsets of one chunk.  Sizes go through LDS so that both the loads of the counters and
+    // the stores of the offsets run along consecutive tiles in consecutive lanes, all of a
+    // thread's loads in flight at once.
+    __shared__ uint32_t s_size[kScanChunk];
+    const uint32_t chunk = blockIdx.x - 1u, base = chunk * kScanChunk;
+    TileCtr mine[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + 1024u * k, last_tile)];
+    for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + 1024u * k, last_tile)];
+    // what the bins of the earlier chunks take
+    uint32_t earlier = 0;
+    for (uint32_t i = tid; i < base; i += 8192) { // (base is a multiple of 8192: no bounds to check)
+        uint32_t sz[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s_size[tid + 1024 * k] = (base + (uint32_t)tid + 1024u * k < a.n_tiles) ? bin_size(mine[k]) : 0u;
-        __syncthreads();
-        uint32_t v[8], sum = 0;
+        for (int k = 0; k < 8; ++k) sz[k] = bin_size(a, i + 1024u * k);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = s_size[8 * tid + k];
-            sum += v[k];
-        }
-        const uint32_t incl = wave_inclusive_scan(sum, lane);
-        if (lane == 63) s_part[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            const uint32_t p = s_part[w];
-            if (w < wave) wbase += p;
-            tot += p;
-        }
-        const uint32_t carry = s_carry;
-        uint32_t run = carry + wbase + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            s_size[8 * tid + k] = run; // the tile's offset from here on
-            run += v[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + (uint32_t)tid + 1024u * k;
-            const uint32_t off = s_size[tid + 1024 * k], c0 = mine[k].cnt[0], c1 = mine[k].cnt[1], c2 = mine[k].cnt[2];
-            if (i < a.n_tiles) a.bin_start[i] = make_uint4(off, off + c0, off + c0 + c1, off + c0 + c1 + c2);
-        }
-        if (tid == 0) s_carry = carry + tot;
-        __syncthreads();
+        for (int k = 0; k < 8; ++k) earlier += sz[k];
     }
-    if (tid == 0) {
-        const uint32_t total = s_carry;
+    const uint32_t carry = block_sum(earlier, s_part, lane, wave);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_size[tid + 1024 * k] = (base + (uint32_t)tid + 1024u * k < a.n_tiles) ? bin_size(mine[k]) : 0u;
+    __syncthreads();
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = s_size[8 * tid + k];
+        sum += v[k];
+    }
+    const uint32_t incl = wave_inclusive_scan(sum, lane);
+    __syncthreads(); // (block_sum's s_part has been read by everybody)
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t p = s_part[w];
+        if (w < wave) wbase += p;
+        tot += p;
+    }
+    uint32_t run = carry + wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s_size[8 * tid + k] = run; // the tile's offset from here on
+        run += v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t i = base + (uint32_t)tid + 1024u * k;
+        const uint32_t off = s_size[tid + 1024 * k], c0 = mine[k].cnt[0], c1 = mine[k].cnt[1], c2 = mine[k].cnt[2];
+        if (i < a.n_tiles) a.bin_start[i] = make_uint4(off, off + c0, off + c0 + c1, off + c0 + c1 + c2);
+    }
+    if (tid == 0 && chunk + 1u == chunks) {
+        const uint32_t total = carry + tot;
         a.counters->total_pairs = total;
         if (total > a.bin_capacity) atomicOr(&a.counters->overflow, kOverflowBins);
     }
@@ -1087,7 +1130,8 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s)
 
 hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(3), dim3(1024), 0, s, a);
+    const uint32_t chunks = a.n_tiles > kScanChunk ? (a.n_tiles + kScanChunk - 1u) / kScanChunk : 1u;
+    hipLaunchKernelGGL(k_scan, dim3(1u + 2u * chunks), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
