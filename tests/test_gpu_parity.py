@@ -225,6 +225,25 @@ def test_config4_bands_of_an_8k_aspect_frame(orc):
     assert np.array_equal(color, ref["color"]) and np.array_equal(depth.view(np.uint32), ref["depth"].view(np.uint32))
 
 
+def test_frame_with_more_than_8192_tiles_and_crowds_of_large_triangles(orc):
+    """4096 x 2112 is 128 x 66 = 8448 tiles: bin offsets and launch order are worked out by several
+    workgroups.  Spheres close to the camera put hundreds of triangles that span more than four
+    tiles on the list of late bin entries; some of them cross the near plane and arrive as fans."""
+    s = scenes.sphere_field_scene(40, 11, 6.0, (-14.0, -0.6), 4096, 2112, n_textures=2, tex_size=64, name="near-spheres")
+    w, h = s.size
+    ref = orc.render(s, orc.to_model(s.transforms), *orc.camera(s.camera, w, h), w, h, threads=8)
+    with api.HipDrawer(w, h, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        assert d.stats()["tiles"] == 8448
+        parts = d.tile_parts()
+        assert parts[:, 4].sum() > 2000, "the scene is meant to produce many late entries"
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+    assert_frames_equal(got, ref, what="8448 tiles")
+
+
 def test_frames_in_flight(orc):
     """Frames enqueued back to back without a host wait: every image must hold exactly its frame,
     also when the first frames overflow their work buffers and are drawn again after the fact
