@@ -106,7 +106,9 @@ typedef struct {
     sxe_transform transform;
 } sxe_instance;
 
-/* Per-kernel device times of the last synchronised frame, milliseconds (needs SXE_FLAG_TIMING). */
+/* Per-kernel device times of the last synchronised frame, milliseconds (needs SXE_FLAG_TIMING).
+ * A rotation-system update is applied by the frame's first kernel and counted in object_ms;
+ * transform_ms is 0. */
 typedef struct {
     float transform_ms, object_ms, setup_ms, scan_ms, bin_ms, raster_shade_ms, frame_ms;
 } sxe_timings;
@@ -149,7 +151,9 @@ int sxe_update_uniforms(sxe_ctx *ctx, const float *models, uint32_t n);
  * run on the device: uploads n transforms and derives the model matrices there. */
 int sxe_update_transforms(sxe_ctx *ctx, const sxe_transform *transforms, uint32_t n);
 /* Rotation::run (src/systems/rotation.rs:26-37) on the device-resident transforms, with a
- * counter-based PRNG in place of thread_rng and a caller-supplied frame delta in ms. */
+ * counter-based PRNG in place of thread_rng and a caller-supplied frame delta in ms.  The update
+ * is carried out by the first kernel of the next sxe_draw (or at once by whatever call reads or
+ * writes transforms or model matrices before that). */
 int sxe_rotation_system(sxe_ctx *ctx, uint64_t seed, uint32_t frame, float delta_ms);
 /* The same for n_frames consecutive frames in one launch (identical arithmetic, applied in frame
  * order): what a process that renders only every N-th frame of an animation needs. */

@@ -122,6 +122,12 @@ struct sxe_ctx {
     sxe_timings timing_totals = {};
     uint64_t timed_frames = 0;
     uint32_t timing_stride = 1; // events are recorded for every timing_stride-th frame
+    // a rotation-system update that has been asked for but not launched: the next frame's first
+    // kernel applies it (anything else that touches transforms or matrices launches it first)
+    bool rot_pending = false;
+    uint64_t rot_seed = 0;
+    uint32_t rot_first = 0, rot_n = 0;
+    float rot_delta_ms = 0.0f;
     sxe_frame_stats stats = {};
     uint32_t redraws = 0;
 };
@@ -385,7 +391,23 @@ ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
     oa.n_zero = 0;
     oa.counters = c->counters.p;
     oa.g = c->g;
+    oa.transforms = c->transforms.p;
+    oa.models_rw = c->models.p;
+    oa.rot_seed = 0;
+    oa.rot_first = oa.rot_n = 0;
+    oa.rot_delta_ms = 0.0f;
     return oa;
+}
+
+// Launches a deferred rotation-system update on its own (the frame it was meant for is not the
+// next thing to happen to the transforms).
+int flush_rotation(sxe_ctx *c)
+{
+    if (!c->rot_pending) return SXE_OK;
+    c->rot_pending = false;
+    SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, c->rot_seed, c->rot_first, c->rot_n,
+                                      c->rot_delta_ms, c->stream));
+    return SXE_OK;
 }
 
 // Per-kernel events cost a few microseconds each; a context may ask for them on a sample of the frames.
@@ -407,6 +429,13 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     {
         ObjectArgs oa = object_args(c, fs);
         oa.objects = fresh ? 1u : 0u;
+        if (fresh && c->rot_pending) {
+            oa.rot_seed = c->rot_seed;
+            oa.rot_first = c->rot_first;
+            oa.rot_n = c->rot_n;
+            oa.rot_delta_ms = c->rot_delta_ms;
+            c->rot_pending = false;
+        }
         oa.n_zero = (uint32_t)(9 * ntc); // the TileCtr of every tile (8 words), then the late-fill counters
         SXE_HIP(c, launch_object(oa, s));
     }
@@ -789,6 +818,8 @@ int sxe_update_drawables(sxe_ctx *c, const sxe_drawable *drawables, uint32_t n)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
+    rc = flush_rotation(c);
+    if (rc) return rc;
     if (n && !drawables) return fail(c, SXE_E_INVALID, "null drawable array");
     std::vector<HostMesh> hm(n);
     std::vector<HostObject> ho(n);
@@ -804,6 +835,8 @@ int sxe_update_instances(sxe_ctx *c, const sxe_mesh_desc *meshes, uint32_t n_mes
 {
     int rc = check_ctx(c);
     if (rc) return rc;
+    rc = flush_rotation(c);
+    if (rc) return rc;
     if ((n_meshes && !meshes) || (n_instances && !instances)) return fail(c, SXE_E_INVALID, "null array");
     std::vector<HostMesh> hm(n_meshes);
     std::vector<HostObject> ho(n_instances);
@@ -816,6 +849,8 @@ int sxe_update_instances(sxe_ctx *c, const sxe_mesh_desc *meshes, uint32_t n_mes
 int sxe_update_uniforms(sxe_ctx *c, const float *models, uint32_t n)
 {
     int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = flush_rotation(c);
     if (rc) return rc;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "update_uniforms before update_drawables");
     if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u model matrices for %u objects", n, c->n_objects);
@@ -830,6 +865,8 @@ int sxe_update_uniforms(sxe_ctx *c, const float *models, uint32_t n)
 int sxe_update_transforms(sxe_ctx *c, const sxe_transform *transforms, uint32_t n)
 {
     int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = flush_rotation(c);
     if (rc) return rc;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "update_transforms before update_drawables");
     if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u transforms for %u objects", n, c->n_objects);
@@ -856,19 +893,15 @@ int sxe_rotation_system_span(sxe_ctx *c, uint64_t seed, uint32_t first_frame, ui
     if (n_frames == 0) return SXE_OK;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "rotation_system before update_drawables");
     if (!c->have_transforms) return fail(c, SXE_E_STATE, "model matrices were set directly; no transforms to rotate");
-    // the update belongs to the frame drawn next: its events live in that frame's slot
-    if (c->frames_enqueued - c->frames_retired >= (uint64_t)kFrameSlots) {
-        rc = retire_oldest(c);
-        if (rc) return rc;
-    }
-    FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
-    const bool timing = frame_is_timed(c, c->frames_enqueued);
-    if (timing) SXE_HIP(c, hipEventRecord(fs.ev_tr[0], c->stream));
-    SXE_HIP(c, launch_rotation_system(c->transforms.p, c->models.p, c->n_objects, seed, frame, n_frames, delta_ms, c->stream));
-    if (timing) {
-        SXE_HIP(c, hipEventRecord(fs.ev_tr[1], c->stream));
-        fs.transform_timed = true;
-    }
+    // The update is applied by the first kernel of the frame drawn next; an update that is already
+    // waiting goes first, on its own.
+    rc = flush_rotation(c);
+    if (rc) return rc;
+    c->rot_pending = true;
+    c->rot_seed = seed;
+    c->rot_first = frame;
+    c->rot_n = n_frames;
+    c->rot_delta_ms = delta_ms;
     return SXE_OK;
 }
 
@@ -973,6 +1006,8 @@ int sxe_read_clip_positions(sxe_ctx *c, float *clip, size_t size_bytes)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
+    rc = flush_rotation(c);
+    if (rc) return rc;
     if (!c->have_scene || !c->have_camera) return fail(c, SXE_E_STATE, "read_clip_positions needs a scene and a camera");
     const size_t need = (size_t)c->n_inst_vertices * 16;
     if (!clip || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
@@ -992,6 +1027,8 @@ int sxe_read_models(sxe_ctx *c, float *models, size_t size_bytes)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
+    rc = flush_rotation(c);
+    if (rc) return rc;
     if (!c->have_scene) return fail(c, SXE_E_STATE, "no scene");
     const size_t need = (size_t)c->n_objects * 64;
     if (!models || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
@@ -1003,6 +1040,8 @@ int sxe_read_models(sxe_ctx *c, float *models, size_t size_bytes)
 int sxe_read_transforms(sxe_ctx *c, sxe_transform *transforms, size_t size_bytes)
 {
     int rc = check_ctx(c);
+    if (rc) return rc;
+    rc = flush_rotation(c);
     if (rc) return rc;
     if (!c->have_scene || !c->have_transforms) return fail(c, SXE_E_STATE, "no device-resident transforms");
     const size_t need = (size_t)c->n_objects * sizeof(sxe_transform);

@@ -27,6 +27,32 @@ namespace sxe {
 // Per-object kernels
 // ------------------------------------------------------------------------------------------
 
+__device__ inline void store_model(float *models, uint32_t i, const Mat4 &R)
+{
+    float4 *dst = reinterpret_cast<float4 *>(models + 16 * (size_t)i);
+    for (int c = 0; c < 4; ++c) dst[c] = make_float4(R.m[4 * c], R.m[4 * c + 1], R.m[4 * c + 2], R.m[4 * c + 3]);
+}
+
+// Rotation::run (src/systems/rotation.rs:26-37) for object i, `n_frames` consecutive updates of it,
+// followed by to_ubo (src/components/transform.rs:69-80).  Stores transform and model matrix.
+__device__ inline Mat4 rotate_object(sxe_transform *t, float *models, uint32_t i, uint64_t seed, uint32_t frame,
+                                     uint32_t n_frames, float delta_ms)
+{
+    sxe_transform tr = t[i];
+    const float delta_time = delta_ms * 0.01f;
+    Quat q = {tr.rotation[0], tr.rotation[1], tr.rotation[2], tr.rotation[3]};
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const float r = rand01(seed, frame + f, i);
+        const float ud = r * delta_time * 2.0f;
+        q = mul(q, quat_from_euler_deg(2.0f * ud, 10.0f * ud, 20.0f * ud));
+    }
+    tr.rotation[0] = q.s; tr.rotation[1] = q.x; tr.rotation[2] = q.y; tr.rotation[3] = q.z;
+    t[i] = tr;
+    const Mat4 M = model_matrix(tr.position, tr.scale, q);
+    store_model(models, i, M);
+    return M;
+}
+
 // PVM per object, plus: is the whole object certainly invisible?  The eight corners of the mesh's
 // bounding box are transformed like vertices; if all of them lie outside one plane of the view
 // volume by more than a bound on the rounding error of such a transform, every vertex of the mesh
@@ -41,10 +67,15 @@ __global__ void k_object(ObjectArgs a)
     if (i < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t *>(a.counters)[i] = 0u;
     if (i >= a.n || !a.objects) return;
     Mat4 M;
-    const float4 *src = reinterpret_cast<const float4 *>(a.models + 16 * (size_t)i);
-    for (int c = 0; c < 4; ++c) {
-        const float4 v = src[c];
-        M.m[4 * c] = v.x; M.m[4 * c + 1] = v.y; M.m[4 * c + 2] = v.z; M.m[4 * c + 3] = v.w;
+    if (a.rot_n) {
+        // the rotation system's update of this frame rides along: one launch less per frame
+        M = rotate_object(a.transforms, a.models_rw, i, a.rot_seed, a.rot_first, a.rot_n, a.rot_delta_ms);
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(a.models + 16 * (size_t)i);
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = src[c];
+            M.m[4 * c] = v.x; M.m[4 * c + 1] = v.y; M.m[4 * c + 2] = v.z; M.m[4 * c + 3] = v.w;
+        }
     }
     const Mat4 R = mul(a.pv, M);
     float4 *dst = reinterpret_cast<float4 *>(a.pvm + 16 * (size_t)i);
@@ -84,12 +115,6 @@ __global__ void k_object(ObjectArgs a)
     a.visible[i] = vis ? 1 : 0;
 }
 
-__device__ inline void store_model(float *models, uint32_t i, const Mat4 &R)
-{
-    float4 *dst = reinterpret_cast<float4 *>(models + 16 * (size_t)i);
-    for (int c = 0; c < 4; ++c) dst[c] = make_float4(R.m[4 * c], R.m[4 * c + 1], R.m[4 * c + 2], R.m[4 * c + 3]);
-}
-
 // Transform::to_ubo for every object (src/components/transform.rs:69-80, loop at src/main.rs:237-244).
 __global__ void k_transform_to_model(const sxe_transform *__restrict__ t, float *__restrict__ models, uint32_t n)
 {
@@ -102,22 +127,12 @@ __global__ void k_transform_to_model(const sxe_transform *__restrict__ t, float 
 
 // Rotation::run (src/systems/rotation.rs:26-37), `n_frames` consecutive updates of it, followed
 // by to_ubo.
-__global__ void k_rotation_system(sxe_transform *__restrict__ t, float *__restrict__ models, uint32_t n,
+__global__ void k_rotation_system(sxe_transform *t, float *models, uint32_t n,
                                   uint64_t seed, uint32_t frame, uint32_t n_frames, float delta_ms)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    sxe_transform tr = t[i];
-    const float delta_time = delta_ms * 0.01f;
-    Quat q = {tr.rotation[0], tr.rotation[1], tr.rotation[2], tr.rotation[3]};
-    for (uint32_t f = 0; f < n_frames; ++f) {
-        const float r = rand01(seed, frame + f, i);
-        const float ud = r * delta_time * 2.0f;
-        q = mul(q, quat_from_euler_deg(2.0f * ud, 10.0f * ud, 20.0f * ud));
-    }
-    tr.rotation[0] = q.s; tr.rotation[1] = q.x; tr.rotation[2] = q.y; tr.rotation[3] = q.z;
-    t[i] = tr;
-    store_model(models, i, model_matrix(tr.position, tr.scale, q));
+    rotate_object(t, models, i, seed, frame, n_frames, delta_ms);
 }
 
 // ------------------------------------------------------------------------------------------

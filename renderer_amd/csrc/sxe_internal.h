@@ -142,6 +142,13 @@ struct ObjectArgs {
     uint32_t n_zero;
     FrameCounters *counters;     // cleared as well
     FrameGeom g;
+    // Rotation::run (src/systems/rotation.rs:26-37) for rot_n consecutive frames, applied to the
+    // transforms before the matrices are derived (rot_n == 0: the model matrices are read as they are)
+    sxe_transform *transforms;
+    float *models_rw;
+    uint64_t rot_seed;
+    uint32_t rot_first, rot_n;
+    float rot_delta_ms;
 };
 
 // Per-tile bookkeeping of a frame.  A tile's bin is a range of bin_size entries of the bin array

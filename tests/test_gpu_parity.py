@@ -275,7 +275,7 @@ def test_frames_in_flight(orc):
                 refs.append(orc.render(s, orc.to_model(t), view, proj, w, h))
             d.sync()
             sums, frames = d.timing_totals()
-            assert frames == 2 and sums["raster_shade_ms"] > 0.0 and sums["transform_ms"] > 0.0
+            assert frames == 2 and sums["raster_shade_ms"] > 0.0 and sums["object_ms"] > 0.0
             with pytest.raises(api.SxeError):
                 d.set_timing_stride(0)
             for img in range(n_images):
