@@ -126,8 +126,18 @@ def test_device_transform_kernels(orc):
         d.update_camera(s.camera)
         d.draw(1)
         got = {"color": d.read_color(1), "depth": d.read_depth(1), "prim": d.read_coverage(1)}
+        ref = orc.render(s, orc.to_model(t), *orc.camera(s.camera, w, h), w, h)
+        assert_frames_equal(got, ref, what="after 12 rotation steps")
+        # an update that is followed by a draw is carried out by the frame's first kernel: the
+        # transforms and matrices in memory must come out the same
+        d.rotation_system(3, 12, 16.0)
+        d.draw(0)
+        orc.rotation_system(t, 3, 12, 16.0)
+        assert d.read_transforms().tobytes() == t.tobytes()
+        assert d.read_models().tobytes() == orc.to_model(t).tobytes()
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
     ref = orc.render(s, orc.to_model(t), *orc.camera(s.camera, w, h), w, h)
-    assert_frames_equal(got, ref, what="after 12 rotation steps")
+    assert_frames_equal(got, ref, what="after 13 rotation steps")
 
 
 def test_moving_camera(orc):
