@@ -130,6 +130,11 @@ struct sxe_ctx {
     float rot_delta_ms = 0.0f;
     sxe_frame_stats stats = {};
     uint32_t redraws = 0;
+    // The clip kernel is launched only while frames have triangles to clip: after kClipQuiet
+    // frames without any it is left out, and the first frame that would have needed it reports
+    // an overflow and is drawn again (like a frame whose work buffers were too small).
+    bool clip_enabled = true;
+    uint32_t clip_quiet = 0;
 };
 
 namespace {
@@ -363,6 +368,8 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     c->n_inst_vertices = inst_vtx;
     c->have_transforms = true;
     c->have_scene = true;
+    c->clip_enabled = true;
+    c->clip_quiet = 0;
 
     // first guess for the work buffers; sxe_sync grows them and redraws when a frame needs more
     // every setup work item owns 256 record slots; fans of clipped triangles follow them
@@ -378,7 +385,7 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
 
 ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
 {
-    ObjectArgs oa;
+    ObjectArgs oa{};
     oa.models = c->models.p;
     oa.pv = c->pv;
     oa.pvm = fs.pvm.p;
@@ -441,7 +448,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     }
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_OBJECT], s));
 
-    SetupArgs sa;
+    SetupArgs sa{};
     sa.vertices = c->vertices.p;
     sa.indices = c->indices.p;
     sa.meshes = c->meshes.p;
@@ -466,11 +473,12 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sa.walk_list = c->walk_list.p;
     sa.bin_keys = c->bin_keys.p;
     sa.counters = c->counters.p;
+    sa.clip_off = c->clip_enabled ? 0u : 1u; // (k_setup must know whether k_clip follows)
     SXE_HIP(c, launch_setup(sa, s));
-    SXE_HIP(c, launch_clip(sa, s));
+    if (c->clip_enabled) SXE_HIP(c, launch_clip(sa, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SETUP], s));
 
-    ScanArgs sc;
+    ScanArgs sc{};
     sc.blk_count = c->blk_count.p;
     sc.n_blocks = c->n_blocks;
     sc.tiles = sa.tiles;
@@ -482,7 +490,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     SXE_HIP(c, launch_scan(sc, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SCAN], s));
 
-    BinArgs ba;
+    BinArgs ba{};
     ba.g = c->g;
     ba.blk_count = c->blk_count.p;
     ba.n_blocks = c->n_blocks;
@@ -505,7 +513,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     SXE_HIP(c, launch_bin(ba, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BIN], s));
 
-    RasterArgs ra;
+    RasterArgs ra{};
     ra.g = c->g;
     ra.tile_launch = c->tile_launch.p;
     ra.bins = c->bins.p;
@@ -543,6 +551,10 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
 int grow_for(sxe_ctx *c, const FrameSlot &fs)
 {
     const FrameCounters &k = *fs.h_counters;
+    if (k.overflow & kOverflowNoClip) {
+        c->clip_enabled = true;
+        c->clip_quiet = 0;
+    }
     // a full clip list hides how many fans its overflow would have produced: at most 7 each
     const size_t fans = std::max<size_t>(k.fan_records, k.clip_count > c->fan_capacity ? (size_t)k.clip_count * kMaxFan : 0);
     const size_t need_fan = fans + fans / 4 + 1024;
@@ -589,6 +601,12 @@ int retire_oldest(sxe_ctx *c)
     fs.pending = false;
     c->frames_retired++;
     const FrameCounters &k = *fs.h_counters;
+    constexpr uint32_t kClipQuiet = 8;
+    if (k.clip_count) {
+        c->clip_quiet = 0;
+    } else if (c->clip_enabled && ++c->clip_quiet >= kClipQuiet) {
+        c->clip_enabled = false;
+    }
     c->stats.prims = c->n_prims;
     c->stats.records = k.total_records;
     c->stats.bin_entries = k.total_pairs;

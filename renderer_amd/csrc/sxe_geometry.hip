@@ -609,7 +609,9 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // order) and are queued for k_clip ----
     if (state == CLIP) {
         const uint32_t at = atomicAdd(&a.counters->clip_count, 1u);
-        if (at < a.fan_capacity) {
+        if (a.clip_off) {
+            atomicOr(&a.counters->overflow, kOverflowNoClip);
+        } else if (at < a.fan_capacity) {
             ClipItem it;
             it.inst = bd.inst; it.tri = t; it.slot = slot;
             a.clip_list[at] = it;

@@ -33,6 +33,7 @@ constexpr uint32_t kDebugMask = 63u << 26;
 
 // overflow bits of FrameCounters::overflow
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
+constexpr uint32_t kOverflowNoClip = 4u; // a triangle needs clipping in a frame enqueued without the clip kernel
 
 struct MeshDev {
     uint32_t vtx_base, n_vtx, idx_base, n_tri;
@@ -191,6 +192,7 @@ struct SetupArgs {
     ShadeRec *shade;
     ColorRec *color;
     uint32_t fan_capacity;     // records available past slot 256 * n_blocks; also the clip list's length
+    uint32_t clip_off;         // the clip kernel does not follow: a triangle that needs it voids the frame
     ClipItem *clip_list;
     uint32_t *bin_keys;        // per order slot: where k_bin files the triangle (kBinKey*)
     uint32_t *walk_list;       // slots of the triangles over more than four tiles and of the fan triangles

@@ -322,6 +322,39 @@ def test_frames_in_flight_with_late_overflow(orc):
             assert_frames_equal(got, refs[img], what="late overflow, image %d" % img)
 
 
+def test_clipping_that_appears_after_quiet_frames(orc):
+    """The clip kernel is left out after some frames without a triangle to clip; the first frame
+    that needs it again must still come out right (it is drawn again), also with frames in flight."""
+    s = scenes.cube_scene(160, 120)
+    w, h = s.size
+    view, proj = orc.camera(s.camera, w, h)
+    far = s.transforms.copy()
+    near = s.transforms.copy()
+    near["position"][0] = (0.1, 0.0, -0.45)  # the cube now straddles the near plane
+    with api.HipDrawer(w, h, n_images=2, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        for f in range(12):
+            d.draw(f & 1)
+        d.sync()
+        assert d.stats()["redraws"] == 0
+        d.update_transforms(near)
+        d.draw(0)
+        d.update_transforms(far)
+        d.draw(1)
+        d.update_transforms(near)
+        d.draw(0)
+        d.sync()
+        assert d.stats()["redraws"] >= 1
+        got_near = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+        got_far = {"color": d.read_color(1), "depth": d.read_depth(1), "prim": d.read_coverage(1)}
+    ref_near = orc.render(s, orc.to_model(near), view, proj, w, h)
+    ref_far = orc.render(s, orc.to_model(far), view, proj, w, h)
+    assert not np.array_equal(ref_near["color"], ref_far["color"])
+    assert_frames_equal(got_near, ref_near, what="cube across the near plane")
+    assert_frames_equal(got_far, ref_far, what="cube back in front")
+
+
 def test_error_behaviour(orc):
     s = scenes.cube_scene(64, 64)
     with api.HipDrawer(64, 64) as d:
