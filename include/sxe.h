@@ -211,6 +211,11 @@ void sxe_transform_to_model(const sxe_transform *t, float model[16]);    /* tran
 void sxe_camera_matrices(const sxe_transform *camera, float fov_deg, float aspect, float z_near,
                          float z_far, float view[16], float proj[16]);
 
+/* The linear -> sRGB8 encoder of the tile kernel (table and lookup), evaluated on the host: lets
+ * a test check it against the threshold definition for any float without a device (no
+ * counterpart in the reference, whose encode happens in the Vulkan driver's output merger). */
+int sxe_srgb_encode_host(const float *x, uint8_t *codes, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

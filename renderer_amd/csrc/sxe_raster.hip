@@ -42,11 +42,10 @@ __device__ inline uint32_t srgb_encode_lds(const uint32_t *enc, float x)
 __device__ uint4 g_srgb_encode[kEncPadded / 4];
 
 // Builds the bucket table from the threshold list; fails if a bucket would need two comparisons.
-static hipError_t upload_encode_table()
+static bool build_encode_table(uint32_t *table)
 {
-    static uint32_t table[kEncPadded];
     auto bits_of = [](float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; };
-    if ((int)(bits_of(SXE_SRGB_ENCODE_THR[0]) >> 16) < kEncKeyLo || !(SXE_SRGB_ENCODE_THR[254] < 1.0f)) return hipErrorInvalidValue;
+    if ((int)(bits_of(SXE_SRGB_ENCODE_THR[0]) >> 16) < kEncKeyLo || !(SXE_SRGB_ENCODE_THR[254] < 1.0f)) return false;
     int k = 0; // thresholds below the current bucket
     table[0] = 0x10000u;
     for (int i = 1; i <= kEncKeyHi - kEncKeyLo; ++i) {
@@ -58,14 +57,31 @@ static hipError_t upload_encode_table()
             ++k;
             ++inside;
         }
-        if (inside > 1) return hipErrorInvalidValue;
+        if (inside > 1) return false;
         table[i] = entry;
     }
-    if (k != 255) return hipErrorInvalidValue;
+    if (k != 255) return false;
     for (int i = kEncEntries - 1; i < kEncPadded; ++i) table[i] = 255u << 24 | 0x10000u;
+    return true;
+}
+
+static hipError_t upload_encode_table()
+{
+    static uint32_t table[kEncPadded];
+    if (!build_encode_table(table)) return hipErrorInvalidValue;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_encode), table, sizeof(table));
 }
 
+// The same lookup as srgb_encode_lds, on the host (for tests of the table without a device).
+static uint32_t srgb_encode_host(const uint32_t *enc, float x)
+{
+    int bits;
+    __builtin_memcpy(&bits, &x, 4);
+    int idx = (bits >> 16) - (kEncKeyLo - 1);
+    idx = idx < 0 ? 0 : (idx > kEncEntries - 1 ? kEncEntries - 1 : idx);
+    const uint32_t e = enc[idx];
+    return (e >> 24) + (((uint32_t)bits & 0xFFFFu) >= (e & 0x1FFFFu) ? 1u : 0u);
+}
 
 static hipError_t ensure_tables()
 {
@@ -670,3 +686,12 @@ hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 }
 
 } // namespace sxe
+
+extern "C" int sxe_srgb_encode_host(const float *x, uint8_t *codes, size_t n)
+{
+    static uint32_t table[sxe::kEncPadded];
+    static const bool ok = sxe::build_encode_table(table);
+    if (!ok || (n && (!x || !codes))) return SXE_E_INVALID;
+    for (size_t i = 0; i < n; ++i) codes[i] = (uint8_t)sxe::srgb_encode_host(table, x[i]);
+    return SXE_OK;
+}

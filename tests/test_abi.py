@@ -115,3 +115,38 @@ def test_scene_builders():
     assert s1.transforms.tobytes() == s.transforms.tobytes()
     d = s.drawables()
     assert len(d) == 100 and len(d[0].vertices) == 561
+
+
+def test_srgb_encode_table_equals_the_threshold_definition(orc):
+    """The tile kernel encodes linear colour with a bucket table over the float bits.  Its host
+    twin (same table builder, same lookup) must agree with the oracle's encoder -- the number of
+    thresholds <= x -- on every float next to a code boundary and on a large random sample."""
+    L = api.lib()
+    L.sxe_srgb_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    xs = []
+    # code boundaries: bisect the oracle's encoder between 0 and 1 for every code step
+    for code in range(1, 256):
+        lo, hi = np.float32(0.0).view(np.uint32), np.float32(1.0).view(np.uint32)
+        lo, hi = int(lo), int(hi)
+        while hi - lo > 1:  # positive floats order like their bit patterns
+            mid = (lo + hi) // 2
+            if orc.srgb_encode(float(np.uint32(mid).view(np.float32))) >= code:
+                hi = mid
+            else:
+                lo = mid
+        xs.extend(range(max(hi - 3, 0), hi + 4))
+    near = np.array(xs, dtype=np.uint32).view(np.float32)
+    rng = np.random.default_rng(5)
+    sample = np.concatenate([
+        near,
+        rng.uniform(0.0, 1.0, 200000).astype(np.float32),
+        (rng.uniform(0.0, 1.0, 50000) ** 4).astype(np.float32),          # dense near zero
+        np.array([0.0, -0.0, 1.0, 1.0000001, 2.0, 1e-30, 1e-45, -1e-3, 0.00012207031, 0.0031308, 0.5], dtype=np.float32),
+    ])
+    sample = np.ascontiguousarray(sample)
+    got = np.zeros(len(sample), dtype=np.uint8)
+    assert L.sxe_srgb_encode_host(sample.ctypes.data, got.ctypes.data, len(sample)) == 0
+    want = np.array([orc.srgb_encode(float(v)) for v in sample], dtype=np.uint8)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "x=%r: table %d, definition %d" % (sample[bad[0]], got[bad[0]], want[bad[0]])
+    assert got[len(near) - 1] == 255 and set(np.unique(got[:len(near)])) == set(range(256))
