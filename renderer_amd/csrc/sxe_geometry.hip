@@ -1,17 +1,19 @@
 // sxe_geometry.hip -- gfx950 kernels of the geometry half of the raster/shade path.
 //
 // Frame pipeline (all on one stream, no host round trip):
-//   k_object        PVM = (P*V)*M per object (standard.vert:28, matrix part) and a conservative
-//                   whole-object visibility test
+//   k_object        the rotation system's update when one is waiting, PVM = (P*V)*M per object
+//                   (standard.vert:28, matrix part), a conservative whole-object visibility test;
+//                   clears the frame's counters
 //   k_setup         one thread per submitted triangle: vertex transform, trivial reject, perspective
 //                   divide, snap, orientation, bounding box, exact coverage test for tiny boxes;
-//                   writes one record per surviving triangle in submission order and counts bin
-//                   entries per screen tile
+//                   writes one record per surviving triangle in submission order and reserves its
+//                   bin entries (per screen tile and pixel-box size class)
 //   k_clip          triangles that cross the near, far or a guard-band plane: Sutherland-Hodgman
 //                   and one record per triangle of the resulting fan
-//   k_scan          exclusive scan of the tile counts, totals, capacity check
-//   k_bin           scatters record slots into the per-tile bins (small boxes to the front of a
-//                   bin, the others to its back)
+//   k_scan          bin offsets (exclusive scan of the tile counts), totals, capacity check, launch
+//                   order of the tiles
+//   k_bin           files record slots in the per-tile bins at the reserved positions, largest size
+//                   class last in a bin; triangles over many tiles take their entries here
 //   k_raster_shade  (sxe_raster.hip) one workgroup per 32x32 tile
 //
 // What the kernels replace in the reference is fixed-function Vulkan state selected at

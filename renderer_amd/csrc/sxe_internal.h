@@ -15,8 +15,6 @@ constexpr int kSetupThreads = 256; // triangles per setup workgroup = record slo
 constexpr int kRasterThreads = 256;
 constexpr float kGuard = 4.0f;     // guard band: x,y are clipped at +-kGuard*w (power of two)
 constexpr int kMaxFan = 7;         // a triangle clipped by six planes has at most 9 corners
-constexpr int kSmallBox = 8;       // bin entries whose pixel box holds <= this many pixels go to the
-                                   // front of a tile's bin, the others to the back
 constexpr int kLaneBox = 24;       // largest pixel box one lane walks alone; larger ones are shared by lanes,
 constexpr int kLaneBoxCrowd = 64;  // unless at least kCrowd lanes of the wave hold boxes up to this size
 constexpr int kCrowd = 24;
@@ -232,7 +230,7 @@ struct BinArgs {
     const uint32_t *bin_start; // [4 * tile + size class]: first bin entry of the class (from k_scan)
     uint32_t *late_fill;       // per tile: how many of its `multi` entries have been placed
     const uint32_t *tile_order;
-    uint4 *tile_launch;        // per launch position: tile, bin offset, bin size, front entries
+    uint4 *tile_launch;        // per launch position: tile, bin offset, bin size
     uint32_t *bins;
     const FrameCounters *counters;
     uint32_t debug;            // kDebug* switches (development only; need kDebugSkipRaster as well)
@@ -240,7 +238,7 @@ struct BinArgs {
 
 struct RasterArgs {
     FrameGeom g;
-    const uint4 *tile_launch;   // workgroup b renders tile tile_launch[b].x; .y bin offset, .z bin size, .w front entries
+    const uint4 *tile_launch;   // workgroup b renders tile tile_launch[b].x; .y bin offset, .z bin size
     const uint32_t *bins;
     const RastRec *rast;
     const WideRec *wide;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     if (a.counters->overflow) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint4 launch = a.tile_launch[blockIdx.x]; // tile, bin offset, bin size, front entries
+    const uint4 launch = a.tile_launch[blockIdx.x]; // tile, bin offset, bin size
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
