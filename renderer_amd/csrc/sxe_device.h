@@ -106,19 +106,29 @@ __device__ inline EdgeStart edge_start(const Tri &t, int32_t i, int32_t j)
     return e;
 }
 
-// Does a narrow triangle cover at least one sample of its (small) pixel box?
+// Does a narrow triangle cover at least one sample of its pixel box?  For boxes of at most four
+// pixels.  The pixels are visited in one sequence, the step to the next one chosen between "one to
+// the right" and "first of the next row" by selects: lanes with boxes of different shapes (1x4,
+// 4x1, 2x2) then take the same four steps instead of the 4 x 4 a pair of nested loops would.
 __device__ inline bool covers_any(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
 {
     const EdgeStart e = edge_start(t, bx0, by0);
-    int32_t R0 = e.R0, R1 = e.R1, R2 = e.R2;
+    const int32_t last = bx1 - bx0;
+    const int32_t cnt = (last + 1) * (by1 - by0 + 1);
+    const int32_t ax0 = -256 * e.ey0, ax1 = -256 * e.ey1, ax2 = -256 * e.ey2; // one pixel to the right
+    // from the last pixel of a row to the first of the next: one down, `last` to the left
+    const int32_t aw0 = 256 * e.ex0 - mul_narrow(ax0, last), aw1 = 256 * e.ex1 - mul_narrow(ax1, last),
+                  aw2 = 256 * e.ex2 - mul_narrow(ax2, last);
+    int32_t E0 = e.R0, E1 = e.R1, E2 = e.R2, col = 0;
     bool any = false;
-    for (int32_t j = by0; j <= by1; ++j) {
-        int32_t E0 = R0, E1 = R1, E2 = R2;
-        for (int32_t i = bx0; i <= bx1; ++i) {
-            any = any || ((E0 | E1 | E2) >= 0);
-            E0 -= 256 * e.ey0; E1 -= 256 * e.ey1; E2 -= 256 * e.ey2; // one pixel to the right
-        }
-        R0 += 256 * e.ex0; R1 += 256 * e.ex1; R2 += 256 * e.ex2;     // one pixel down
+#pragma unroll
+    for (int32_t k = 0; k < 4; ++k) {
+        any = any || (k < cnt && (E0 | E1 | E2) >= 0);
+        const bool wrap = col == last;
+        E0 += wrap ? aw0 : ax0;
+        E1 += wrap ? aw1 : ax1;
+        E2 += wrap ? aw2 : ax2;
+        col = wrap ? 0 : col + 1;
     }
     return any;
 }
