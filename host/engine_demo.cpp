@@ -1,7 +1,7 @@
 // engine_demo.cpp -- the reference's frame loop (start_engine, src/main.rs:140-199) on the C++
 // Drawer/Presenter mirror of include/sxe_drawer.hpp.
 //
-//   engine_demo <scene file> <output .rgba> [output .ppm]
+//   engine_demo <scene file> <output .rgba> [output .ppm or .png]
 //
 // The scene file is written by tests/util.py:write_scene_file (little endian):
 //   "SXES" u32 version(1) | u32 width height n_images n_frames | f32 rotate_deg[3] | f32 camera[10]
@@ -59,7 +59,7 @@ std::vector<ObjectUniformBufferObject> fetch_uniforms(const std::vector<Drawable
 int main(int argc, char **argv)
 {
     if (argc < 3) {
-        std::cerr << "usage: engine_demo <scene file> <output .rgba> [output .ppm]\n";
+        std::cerr << "usage: engine_demo <scene file> <output .rgba> [output .ppm or .png]\n";
         return 2;
     }
     try {
@@ -124,7 +124,11 @@ int main(int argc, char **argv)
         std::ofstream out(argv[2], std::ios::binary);
         out.write(reinterpret_cast<const char *>(last.rgba.data()), (std::streamsize)last.rgba.size());
         if (!out) throw std::runtime_error(std::string("cannot write ") + argv[2]);
-        if (argc > 3) write_ppm(argv[3], last).unwrap();
+        if (argc > 3) {
+            const std::string picture = argv[3];
+            const bool png = picture.size() > 4 && picture.compare(picture.size() - 4, 4, ".png") == 0;
+            (png ? write_png(picture, last) : write_ppm(picture, last)).unwrap();
+        }
         std::cout << "frames " << n_frames << " size " << last.width << "x" << last.height << "\n";
     } catch (const std::exception &e) {
         std::cerr << "engine_demo: " << e.what() << "\n";

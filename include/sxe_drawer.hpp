@@ -16,6 +16,8 @@
 
 #include "sxe.h"
 
+#include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -281,6 +283,74 @@ inline Status write_ppm(const std::string &path, const Image &im)
     }
     good = (std::fclose(f) == 0) && good;
     return good ? Status::Ok() : Status::Err("short write to '" + path + "'");
+}
+
+// PNG (8-bit RGBA, colour type 6) with stored, i.e. uncompressed, deflate blocks: every decoder
+// reads it and it needs no compression library.  The pixels are sRGB-encoded, as the render target
+// is (src/renderer/presenter.rs:472-478), which is what PNG viewers assume.
+namespace detail {
+inline uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n)
+{
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+inline void put32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+inline void chunk(std::vector<uint8_t> &out, const char type[4], const std::vector<uint8_t> &data)
+{
+    put32(out, (uint32_t)data.size());
+    const size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put32(out, crc32(0, out.data() + start, out.size() - start));
+}
+} // namespace detail
+
+inline Status write_png(const std::string &path, const Image &im)
+{
+    if (im.width == 0 || im.height == 0 || (size_t)im.width * im.height * 4 != im.rgba.size())
+        return Status::Err("image does not hold width * height RGBA8 pixels");
+    std::vector<uint8_t> raw; // scanlines, each behind a filter byte 0 (none)
+    raw.reserve(((size_t)im.width * 4 + 1) * im.height);
+    for (uint32_t y = 0; y < im.height; ++y) {
+        raw.push_back(0);
+        const uint8_t *row = im.rgba.data() + (size_t)y * im.width * 4;
+        raw.insert(raw.end(), row, row + (size_t)im.width * 4);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01}; // zlib header, then stored blocks of at most 65535 bytes
+    uint32_t a = 1, b = 0;                 // Adler-32 of the raw data
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)pos, raw.begin() + (std::ptrdiff_t)(pos + n));
+        for (size_t i = pos; i < pos + n; ++i) {
+            a = (a + raw[i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        pos += n;
+    }
+    detail::put32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    detail::put32(ihdr, im.width);
+    detail::put32(ihdr, im.height);
+    ihdr.insert(ihdr.end(), {8, 6, 0, 0, 0}); // bit depth, RGBA, deflate, adaptive filtering, no interlace
+    detail::chunk(out, "IHDR", ihdr);
+    detail::chunk(out, "sRGB", {0}); // rendering intent: perceptual
+    detail::chunk(out, "IDAT", z);
+    detail::chunk(out, "IEND", {});
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return Status::Err("cannot open '" + path + "' for writing");
+    const bool good = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (std::fclose(f) == 0 && good) ? Status::Ok() : Status::Err("short write to '" + path + "'");
 }
 
 } // namespace sxe_host

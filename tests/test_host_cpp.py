@@ -41,6 +41,40 @@ def test_header_compiles_with_warnings_as_errors(tmp_path):
     assert subprocess.run([exe]).returncode == 0
 
 
+def test_png_writer_produces_a_valid_file(tmp_path):
+    """write_png (the Presenter stand-in's file output): chunk CRCs, header fields and the pixels
+    after inflating the stored-deflate stream."""
+    import struct
+    import zlib
+    src = tmp_path / "p.cpp"
+    src.write_text(
+        '#include "sxe_drawer.hpp"\n'
+        'int main(int, char **argv) {\n'
+        '    sxe_host::Image im; im.width = 301; im.height = 77; im.rgba.resize(301 * 77 * 4);\n'
+        '    for (size_t i = 0; i < im.rgba.size(); ++i) im.rgba[i] = (uint8_t)((i * 2654435761u) >> 13);\n'
+        '    return sxe_host::write_png(argv[1], im).ok() ? 0 : 1;\n'
+        '}\n')
+    exe, out = str(tmp_path / "p"), str(tmp_path / "p.png")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", os.path.join(ROOT, "renderer_amd"), "-lsxe_hip", "-Wl,-rpath," + os.path.join(ROOT, "renderer_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    subprocess.check_call([exe, out])
+    d = open(out, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(d):
+        n, = struct.unpack(">I", d[pos:pos + 4])
+        kind, body = d[pos + 4:pos + 8], d[pos + 8:pos + 8 + n]
+        assert zlib.crc32(kind + body) == struct.unpack(">I", d[pos + 8 + n:pos + 12 + n])[0]
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (301, 77, 8, 6, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[2][1]), np.uint8).reshape(77, 301 * 4 + 1)
+    i = np.arange(301 * 77 * 4, dtype=np.uint64)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:], (((i * 2654435761) & 0xFFFFFFFF) >> 13).astype(np.uint8).reshape(77, -1))
+
+
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the behaviour without a GPU")
 def test_host_program_fails_loudly_without_a_gpu(tmp_path):
     p, out, _ = run_demo(tmp_path, scenes.cube_scene(64, 48))
