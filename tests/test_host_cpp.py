@@ -75,6 +75,58 @@ def test_png_writer_produces_a_valid_file(tmp_path):
     assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:], (((i * 2654435761) & 0xFFFFFFFF) >> 13).astype(np.uint8).reshape(77, -1))
 
 
+def test_jpeg_loader_against_an_independent_decoder(tmp_path):
+    """include/sxe_jpeg.hpp (the texture-file loader): baseline files in the usual samplings, with
+    and without restart markers, decode to what an independent decoder gives, up to the few code
+    values by which integer inverse DCTs and chroma interpolation differ; progressive files are
+    refused.  The test images are synthetic (the reference's textures are unavailable LFS pointers)."""
+    Image = pytest.importorskip("PIL.Image")
+    src = tmp_path / "j.cpp"
+    src.write_text(
+        '#include "sxe_jpeg.hpp"\n#include <iostream>\n'
+        'int main(int, char **argv) {\n'
+        '    sxe_host::Image im;\n'
+        '    const sxe_host::Status s = sxe_host::load_jpeg(argv[1], im);\n'
+        '    if (!s) { std::cerr << s.error << "\\n"; return 1; }\n'
+        '    std::cout << im.width << " " << im.height << "\\n";\n'
+        '    std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char *>(im.rgba.data()), (std::streamsize)im.rgba.size());\n'
+        '    return 0;\n}\n')
+    exe = str(tmp_path / "j")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", os.path.join(ROOT, "renderer_amd"), "-lsxe_hip", "-Wl,-rpath," + os.path.join(ROOT, "renderer_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    rng = np.random.default_rng(1)
+
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([128 + 100 * np.sin(x / 17.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 23.0 + 1), 128 + 80 * np.sin((x + y) / 29.0)], -1)
+        return np.clip(a + rng.normal(0, 6, a.shape), 0, 255).astype(np.uint8)
+
+    cases = [("444", dict(subsampling=0, quality=90), (67, 45), 3, 0.1), ("420", dict(subsampling=2, quality=85), (130, 77), 12, 1.5),
+             ("422", dict(subsampling=1, quality=75), (64, 64), 12, 1.5), ("grey", dict(quality=80), (50, 33), 3, 0.1),
+             ("restart", dict(subsampling=2, quality=85, restart_marker_blocks=3), (100, 60), 12, 1.5),
+             ("coarse", dict(subsampling=0, quality=30), (40, 40), 3, 0.1)]
+    for name, opts, (w, h), max_diff, mean_diff in cases:
+        img = Image.fromarray(picture(w, h))
+        if name == "grey":
+            img = img.convert("L")
+        path, out = str(tmp_path / (name + ".jpg")), str(tmp_path / (name + ".rgba"))
+        img.save(path, "JPEG", **opts)
+        p = subprocess.run([exe, path, out], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.split() == [str(w), str(h)], (name, p.stderr)
+        got = np.fromfile(out, np.uint8).reshape(h, w, 4)
+        ref = np.asarray(Image.open(path).convert("RGBA"))
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert (got[..., 3] == 255).all() and d.max() <= max_diff and d.mean() <= mean_diff, (name, d.max(), d.mean())
+    path = str(tmp_path / "progressive.jpg")
+    Image.fromarray(picture(40, 40)).save(path, "JPEG", progressive=True)
+    p = subprocess.run([exe, path, str(tmp_path / "x.rgba")], capture_output=True, text=True)
+    assert p.returncode == 1 and "baseline only" in p.stderr
+    (tmp_path / "junk.jpg").write_bytes(b"\xff\xd8\xff\xdb\x00\x03\x00")
+    p = subprocess.run([exe, str(tmp_path / "junk.jpg"), str(tmp_path / "x.rgba")], capture_output=True, text=True)
+    assert p.returncode == 1 and "jpeg:" in p.stderr
+
+
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the behaviour without a GPU")
 def test_host_program_fails_loudly_without_a_gpu(tmp_path):
     p, out, _ = run_demo(tmp_path, scenes.cube_scene(64, 48))
