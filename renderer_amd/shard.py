@@ -91,3 +91,60 @@ def frame_hash(color):
     a = np.ascontiguousarray(color).view(np.uint8).ravel().astype(np.uint64)
     idx = np.arange(1, a.size + 1, dtype=np.uint64)
     return int(((a + np.uint64(1)) * (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))).sum(dtype=np.uint64))
+
+
+class ViewPool:
+    """Many small views of one scene (the multi-view configuration) on one GPU.
+
+    A 512x512 view of a hundred objects keeps the GPU busy for a few microseconds per kernel, so
+    a single stream spends most of a view waiting for launches.  The pool holds `contexts`
+    independent drawers (own stream, own work buffers, the scene uploaded to each) and deals the
+    views out over them in turn, so that the kernels of several views are in flight at once.
+    Nothing is shared between the contexts and no kernel knows about the others; every view is
+    rendered exactly as a single drawer would render it.
+    """
+
+    def __init__(self, scene, contexts=4, n_images=2, device=0, **drawer_args):
+        from . import api
+        self.size = scene.size
+        self.n_images = n_images
+        self.drawers = []
+        for _ in range(max(1, int(contexts))):
+            d = api.HipDrawer(scene.size[0], scene.size[1], device=device, n_images=n_images, **drawer_args)
+            d.update_scene(scene)
+            self.drawers.append(d)
+
+    def close(self):
+        for d in self.drawers:
+            d.close()
+        self.drawers = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def render(self, cameras, read=None):
+        """Render one view per camera Transform.  `read(drawer, image_index)` turns a finished view
+        into what is returned for it (default: its RGBA8 image); it is called when the view's image
+        is about to be used again and for the rest at the end, always in view order per context."""
+        if read is None:
+            read = lambda d, img: d.read_color(img)  # noqa: E731
+        n = len(cameras)
+        out = [None] * n
+        k_ctx = len(self.drawers)
+        holds = [[None] * self.n_images for _ in range(k_ctx)]  # which view each image holds, unread
+        for i in range(n):
+            c = i % k_ctx
+            img = (i // k_ctx) % self.n_images
+            d = self.drawers[c]
+            if holds[c][img] is not None:
+                out[holds[c][img]] = read(d, img)
+            d.update_camera(cameras[i:i + 1])
+            d.draw(img)
+            holds[c][img] = i
+        for c in range(k_ctx):
+            for v, img in sorted((v, img) for img, v in enumerate(holds[c]) if v is not None):
+                out[v] = read(self.drawers[c], img)
+        return out

@@ -212,6 +212,22 @@ def test_config5_views_share_one_scene(orc):
                 assert_frames_equal(got, ref, what="view %d (rank %d)" % (v, rank))
 
 
+def test_view_pool_renders_every_view_like_a_single_drawer(orc):
+    """Views dealt out over three contexts with two images each: images are reused while later
+    views are in flight, and every view must still equal the oracle's."""
+    from renderer_amd import shard
+    s = scenes.config_scene(5, scale=0.5)
+    w, h = s.size
+    cams = scenes.orbit_cameras(11, 5, radius=30.0, target=(0.0, 0.0, -22.5))
+    models = orc.to_model(s.transforms)
+    with shard.ViewPool(s, contexts=3, n_images=2, coverage=True) as pool:
+        got = pool.render(cams, read=lambda d, img: {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)})
+    assert len(got) == 11
+    for v in range(11):
+        view, proj = orc.camera(cams[v:v + 1], w, h)
+        assert_frames_equal(got[v], orc.render(s, models, view, proj, w, h), what="pooled view %d" % v)
+
+
 def test_config4_bands_of_an_8k_aspect_frame(orc):
     """The sort-first configuration at reduced size: 8 bands of whole tile rows of a 16:9 frame whose
     height is not a multiple of the tile size reassemble to the full frame."""
