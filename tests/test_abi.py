@@ -150,3 +150,36 @@ def test_srgb_encode_table_equals_the_threshold_definition(orc):
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, "x=%r: table %d, definition %d" % (sample[bad[0]], got[bad[0]], want[bad[0]])
     assert got[len(near) - 1] == 255 and set(np.unique(got[:len(near)])) == set(range(256))
+
+
+def test_rust_declarations_cover_the_header():
+    """bindings/rust/sxe-sys/src/lib.rs cannot be compiled here (no Rust toolchain); at least it must
+    declare every function of include/sxe.h with the same number of arguments, and its #[repr(C)]
+    structs must add up to the sizes of the C ones."""
+    rs = open(os.path.join(ROOT, "bindings", "rust", "sxe-sys", "src", "lib.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sxe.h")).read(), flags=re.S)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(sxe_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header)}
+    rs_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (sxe_[a-z0-9_]+)\(([^)]*)\)", rs)}
+    assert sorted(c_fns) == sorted(rs_fns) == declared_symbols()
+
+    def n_args(text):
+        text = text.strip()
+        return 0 if text in ("", "void") else text.count(",") + 1
+    for name in c_fns:
+        assert n_args(c_fns[name]) == n_args(rs_fns[name]), name
+    size = {"u8": 1, "i32": 4, "u32": 4, "f32": 4, "u64": 8, "*": 8, "sxe_transform": 40, "sxe_vertex": 32}
+    align = {"u8": 1, "i32": 4, "u32": 4, "f32": 4, "u64": 8, "*": 8, "sxe_transform": 4, "sxe_vertex": 4}
+    want = {"sxe_vertex": 32, "sxe_transform": 40, "sxe_config": C.sizeof(api.Config), "sxe_drawable": C.sizeof(api.DrawableC),
+            "sxe_timings": C.sizeof(api.Timings), "sxe_frame_stats": C.sizeof(api.FrameStats), "sxe_texture_desc": 16,
+            "sxe_mesh_desc": 32, "sxe_instance": 52}
+    for name, expect in want.items():
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, re.S).group(1)
+        off, biggest = 0, 1
+        for ty in re.findall(r"pub \w+: ([^,\n]+),", body):
+            ty = ty.strip()
+            m = re.match(r"\[(\w+); (\d+)\]", ty)
+            base, count = (m.group(1), int(m.group(2))) if m else (("*" if ty.startswith("*") else ty), 1)
+            a = align[base]
+            off = (off + a - 1) // a * a + size[base] * count
+            biggest = max(biggest, a)
+        assert (off + biggest - 1) // biggest * biggest == expect, name
