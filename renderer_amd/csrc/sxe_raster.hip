@@ -150,10 +150,13 @@ __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
     const int mw = (int)t.width - 1, mh = (int)t.height - 1;
     const int ix0 = min(max((int)fx0, 0), mw), ix1 = min(max((int)fx0 + 1, 0), mw);
     const int iy0 = min(max((int)fy0, 0), mh), iy1 = min(max((int)fy0 + 1, 0), mh);
-    q.i00 = t.offset + (uint32_t)iy0 * t.width + (uint32_t)ix0;
-    q.i10 = t.offset + (uint32_t)iy0 * t.width + (uint32_t)ix1;
-    q.i01 = t.offset + (uint32_t)iy1 * t.width + (uint32_t)ix0;
-    q.i11 = t.offset + (uint32_t)iy1 * t.width + (uint32_t)ix1;
+    // rows and widths are at most 16384 (checked when the textures are set): the full-rate 24-bit
+    // multiply gives the same product as the general one, which costs four times as much
+    const uint32_t row0 = t.offset + __umul24((uint32_t)iy0, t.width), row1 = t.offset + __umul24((uint32_t)iy1, t.width);
+    q.i00 = row0 + (uint32_t)ix0;
+    q.i10 = row0 + (uint32_t)ix1;
+    q.i01 = row1 + (uint32_t)ix0;
+    q.i11 = row1 + (uint32_t)ix1;
     return q;
 }
 
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
                 t = unpack_tri(r, a.wide, slots[k]);
                 nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
                 is_narrow = narrow(t);
-                box_px = (bx1 - bx0 + 1) * (by1 - by0 + 1);
+                box_px = mul_narrow(bx1 - bx0 + 1, by1 - by0 + 1);
             }
             // Boxes of 25 to 64 pixels: when a wave holds many of them its lanes are evenly loaded
             // and walking them lane by lane is the cheapest way; a few among small boxes would keep
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
         const bool in_rect = !(i > cx1 || j < cy0 || j > cy1);
         const bool covered = in_rect && vis[ly * kTile + lx] != kVisEmpty;
         if (in_rect && !covered) {
-            const size_t p = (size_t)j * a.g.width + (size_t)i;
+            const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
             reinterpret_cast<uint32_t *>(a.out_color)[p] = a.clear_code;
             a.out_depth[p] = 1.0f;
             if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int b = 0; b < kResolveBatch; ++b)
             if (live[b]) {
-                const size_t p = (size_t)py[b] * a.g.width + (size_t)px[b];
+                const size_t p = (size_t)(__umul24((uint32_t)py[b], a.g.width) + (uint32_t)px[b]);
                 reinterpret_cast<uint32_t *>(a.out_color)[p] = code[b];
                 a.out_depth[p] = depth[b];
                 if (COVERAGE) a.out_prim[p] = prim[b];
