@@ -3,11 +3,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from renderer_amd import scenes
-from oracle import oracle
+from renderer_amd import api, scenes
 s = scenes.config_scene(3); w, h = s.size
-m = oracle.to_model(s.transforms).reshape(-1, 4, 4).astype(np.float64)
-v, p = oracle.camera(s.camera, w, h)
+m = api.to_model(s.transforms).reshape(-1, 4, 4).astype(np.float64)  # the library's host-side maths
+v, p = api.camera_matrices(s.camera, w, h)
 V = np.array(v, dtype=np.float64).reshape(4, 4).T; P = np.array(p, dtype=np.float64).reshape(4, 4).T
 PVM = P @ V @ np.transpose(m, (0, 2, 1))
 nv = int(s.meshes[0]['n_vertices']); nt = int(s.meshes[0]['n_triangles']) if 'n_triangles' in s.meshes.dtype.names else 1024
