@@ -135,6 +135,16 @@ struct sxe_ctx {
     // an overflow and is drawn again (like a frame whose work buffers were too small).
     bool clip_enabled = true;
     uint32_t clip_quiet = 0;
+    // Per-frame uploads (model matrices, transforms) go through a small ring of pinned buffers: the
+    // caller's memory is only borrowed for the call, and copying it here first lets the transfer run
+    // on the stream without the call waiting for it.
+    struct Staging {
+        void *p = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    } staging[4];
+    uint32_t staging_next = 0;
 };
 
 namespace {
@@ -404,6 +414,29 @@ ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
     oa.rot_first = oa.rot_n = 0;
     oa.rot_delta_ms = 0.0f;
     return oa;
+}
+
+// Copies `bytes` of caller memory to `dst` on the device, asynchronously on the context's stream.
+int stage_upload(sxe_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return SXE_OK;
+    sxe_ctx::Staging &st = c->staging[c->staging_next++ % 4];
+    if (!st.done) SXE_HIP(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.used) SXE_HIP(c, hipEventSynchronize(st.done)); // its previous transfer has long finished
+    if (st.cap < bytes) {
+        if (st.p) SXE_HIP(c, hipHostFree(st.p));
+        st.p = nullptr;
+        st.cap = 0;
+        SXE_HIP(c, hipHostMalloc(&st.p, bytes, hipHostMallocDefault));
+        st.cap = bytes;
+    }
+    memcpy(st.p, src, bytes);
+    // (on the context's own stream: a second stream for the transfers, ordered by events, was
+    // measured slower -- the cross-stream waits cost more than the 25 us transfer they would hide)
+    SXE_HIP(c, hipMemcpyAsync(dst, st.p, bytes, hipMemcpyHostToDevice, c->stream));
+    SXE_HIP(c, hipEventRecord(st.done, c->stream));
+    st.used = true;
+    return SXE_OK;
 }
 
 // Launches a deferred rotation-system update on its own (the frame it was meant for is not the
@@ -783,6 +816,10 @@ void sxe_destroy(sxe_ctx *c)
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
+    for (auto &st : c->staging) {
+        if (st.p) (void)hipHostFree(st.p);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
     for (FrameSlot &fs : c->slots) {
         fs.pvm.release(); fs.visible.release();
         if (fs.h_counters) (void)hipHostFree(fs.h_counters);
@@ -873,9 +910,8 @@ int sxe_update_uniforms(sxe_ctx *c, const float *models, uint32_t n)
     if (!c->have_scene) return fail(c, SXE_E_STATE, "update_uniforms before update_drawables");
     if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u model matrices for %u objects", n, c->n_objects);
     if (n && !models) return fail(c, SXE_E_INVALID, "null matrices");
-    if (n) SXE_HIP(c, hipMemcpyAsync(c->models.p, models, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
-    // the caller's buffer is only borrowed for the call
-    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    rc = stage_upload(c, c->models.p, models, (size_t)n * 64);
+    if (rc) return rc;
     c->have_transforms = false;
     return SXE_OK;
 }
@@ -890,9 +926,9 @@ int sxe_update_transforms(sxe_ctx *c, const sxe_transform *transforms, uint32_t 
     if (n > c->n_objects) return fail(c, SXE_E_CAPACITY, "%u transforms for %u objects", n, c->n_objects);
     if (n && !transforms) return fail(c, SXE_E_INVALID, "null transforms");
     if (n) {
-        SXE_HIP(c, hipMemcpyAsync(c->transforms.p, transforms, (size_t)n * sizeof(sxe_transform), hipMemcpyHostToDevice, c->stream));
+        rc = stage_upload(c, c->transforms.p, transforms, (size_t)n * sizeof(sxe_transform));
+        if (rc) return rc;
         SXE_HIP(c, launch_transform_to_model(c->transforms.p, c->models.p, n, c->stream));
-        SXE_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->have_transforms = (n == c->n_objects) || c->have_transforms;
     return SXE_OK;
