@@ -1075,6 +1075,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
         // the dependent memory round trips of a crowd of them (a mesh close to the camera) are
         // spread over many waves instead of queueing up in one.
         if (a.debug & (kDebugSkipLarge | kDebugSkipAtomic)) return; // development: without the late entries
+        if (blockIdx.x - seg_groups >= a.walk_blocks) return;       // (workgroups launched for the tile list only)
         const uint32_t n_walk = a.counters->walk_count;
         const uint32_t n_slots = a.n_blocks * kSetupThreads;
         const uint32_t wave_id = (blockIdx.x - seg_groups) * 4u + (uint32_t)wave;
