@@ -341,23 +341,31 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     // the frame's counters are final by now: report them to the host without a copy command
     if (blockIdx.x == 0 && a.host_counters && threadIdx.x < sizeof(FrameCounters) / 4)
         reinterpret_cast<uint32_t *>(a.host_counters)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.counters)[threadIdx.x];
-    if (a.counters->overflow) return;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // What the workgroup reads before it can start is requested in one go -- the overflow flag, the
+    // launch record, its share of the tables -- and the flag is acted on behind the first barrier,
+    // when all of it has arrived: one round trip to memory instead of two.
+    const uint32_t overflow = a.counters->overflow;
     const uint4 launch = a.tile_launch[blockIdx.x]; // tile, bin offset, bin size
-    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
+    static_assert(kEncPadded / 4 <= 2 * kRasterThreads, "two table pieces per thread");
+    const uint4 enc_a = g_srgb_encode[tid], enc_b = g_srgb_encode[min(tid + kRasterThreads, kEncPadded / 4 - 1)];
+    const float dec = c_srgb_decode[tid];
+    // (a frame that overflowed has no launch records: tile 0 stands in until the workgroup leaves)
+    const uint32_t tile = overflow ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
     const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
     for (int i = tid; i < kTilePixels; i += kRasterThreads) vis[i] = kVisEmpty;
-    for (int i = tid; i < kEncPadded / 4; i += kRasterThreads) reinterpret_cast<uint4 *>(s_enc)[i] = g_srgb_encode[i];
-    s_dec[tid] = c_srgb_decode[tid];
+    reinterpret_cast<uint4 *>(s_enc)[tid] = enc_a;
+    if (tid + kRasterThreads < kEncPadded / 4) reinterpret_cast<uint4 *>(s_enc)[tid + kRasterThreads] = enc_b;
+    s_dec[tid] = dec;
     if (tid < kTexCache && (uint32_t)tid < a.n_textures) s_tex[tid] = a.textures[tid];
     if (tid == 0) { s_nwq = 0; s_ncov = 0; }
     if (tid >= 1 && tid <= 32) s_magic[tid] = (65536u + (uint32_t)tid - 1u) / (uint32_t)tid;
     __syncthreads();
     SXE_STAMP(1);
+    if (overflow) return;
 
     // rectangle of this tile that exists in the frame and the scissor (inclusive)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
