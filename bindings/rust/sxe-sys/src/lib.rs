@@ -136,6 +136,7 @@ extern "C" {
     pub fn sxe_draw(ctx: *mut sxe_ctx, image_index: u32) -> c_int;
     pub fn sxe_sync(ctx: *mut sxe_ctx) -> c_int;
     pub fn sxe_read_color(ctx: *mut sxe_ctx, image_index: u32, rgba: *mut u8, size_bytes: usize) -> c_int;
+    pub fn sxe_map_color(ctx: *mut sxe_ctx, image_index: u32, rgba: *mut *const u8) -> c_int;
     pub fn sxe_read_depth(ctx: *mut sxe_ctx, image_index: u32, depth: *mut f32, size_bytes: usize) -> c_int;
     pub fn sxe_read_coverage(ctx: *mut sxe_ctx, image_index: u32, prim_ids: *mut u32, size_bytes: usize) -> c_int;
     pub fn sxe_read_clip_positions(ctx: *mut sxe_ctx, clip: *mut f32, size_bytes: usize) -> c_int;

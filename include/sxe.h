@@ -170,6 +170,11 @@ int sxe_sync(sxe_ctx *ctx);
 
 /* ---- readback: stands in for Presenter::present (src/renderer/presenter.rs:415-430) ---- */
 int sxe_read_color(sxe_ctx *ctx, uint32_t image_index, uint8_t *rgba, size_t size_bytes);
+/* The same frame without a copy into caller memory: the library transfers it into pinned memory
+ * of its own and hands out the address (width * height * 4 bytes, valid until the next
+ * sxe_map_color of this image or sxe_destroy).  Several times the rate of sxe_read_color into
+ * pageable memory; what a presenter that only forwards the pixels wants. */
+int sxe_map_color(sxe_ctx *ctx, uint32_t image_index, const uint8_t **rgba);
 int sxe_read_depth(sxe_ctx *ctx, uint32_t image_index, float *depth, size_t size_bytes);
 int sxe_read_coverage(sxe_ctx *ctx, uint32_t image_index, uint32_t *prim_ids, size_t size_bytes);
 /* gl_Position of every vertex (standard.vert:28) in the layout of the reference's concatenated

@@ -256,6 +256,17 @@ class ReadbackPresenter {
         return Status::Ok();
     }
     const Image &frame() const { return frame_; } // the image presented last
+    // present() without the copy into an Image: the pixels stay in the library's pinned buffer
+    // (valid until this image is presented this way again).
+    Status present_view(const uint8_t *&rgba)
+    {
+        const int rc = sxe_map_color(drawer_.context(), current_, &rgba);
+        if (rc != SXE_OK) {
+            const char *m = sxe_last_error(drawer_.context());
+            return Status::Err("present: " + std::string(m ? m : ""));
+        }
+        return Status::Ok();
+    }
 
   private:
     HipDrawer &drawer_;

@@ -27,7 +27,7 @@ EXPORTS = [
     "sxe_default_config", "sxe_create", "sxe_destroy", "sxe_last_error", "sxe_version", "sxe_set_textures",
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
     "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync",
-    "sxe_read_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
+    "sxe_read_color", "sxe_map_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
     "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
     "sxe_camera_matrices", "sxe_srgb_encode_host",
@@ -127,6 +127,7 @@ def lib():
                      "sxe_read_tile_times"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sxe_color_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sxe_map_color.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8))]
         L.sxe_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
         L.sxe_get_timing_totals.argtypes = [C.c_void_p, C.POINTER(Timings), C.POINTER(C.c_uint64)]
         L.sxe_reset_timing_totals.argtypes = [C.c_void_p]
@@ -363,6 +364,15 @@ class HipDrawer:
         out = np.zeros(max(n, 1), dtype=np.uint32)
         self._check(self._L.sxe_read_tile_counts(self._ctx, _p(out), out.nbytes))
         return out[:n]
+
+    def map_color(self, image=0):
+        """The frame as a read-only view of the library's pinned copy (no copy into numpy memory);
+        valid until the next map_color of this image or close()."""
+        ptr = C.POINTER(C.c_uint8)()
+        self._check(self._L.sxe_map_color(self._ctx, image, C.byref(ptr)))
+        a = np.ctypeslib.as_array(ptr, shape=(self.height, self.width, 4))
+        a.flags.writeable = False
+        return a
 
     def tile_parts(self):
         n = int(self.stats()["tiles"])

@@ -52,6 +52,7 @@ struct Image {
     DevBuf<uint8_t> color;
     DevBuf<float> depth;
     DevBuf<uint32_t> prim;
+    uint8_t *h_color = nullptr; // pinned copy handed out by sxe_map_color (allocated on first use)
     bool drawn = false;
 };
 
@@ -815,7 +816,10 @@ void sxe_destroy(sxe_ctx *c)
     c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->walk_list.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
-    for (auto &img : c->images) { img.color.release(); img.depth.release(); img.prim.release(); }
+    for (auto &img : c->images) {
+        img.color.release(); img.depth.release(); img.prim.release();
+        if (img.h_color) (void)hipHostFree(img.h_color);
+    }
     for (auto &st : c->staging) {
         if (st.p) (void)hipHostFree(st.p);
         if (st.done) (void)hipEventDestroy(st.done);
@@ -1044,6 +1048,24 @@ int sxe_reset_timing_totals(sxe_ctx *c)
 int sxe_read_color(sxe_ctx *c, uint32_t image_index, uint8_t *rgba, size_t size_bytes)
 {
     return read_image_plane(c, image_index, rgba, size_bytes, 0);
+}
+
+int sxe_map_color(sxe_ctx *c, uint32_t image_index, const uint8_t **rgba)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!rgba) return fail(c, SXE_E_INVALID, "null result pointer");
+    if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
+    Image &img = c->images[image_index];
+    if (!img.drawn) return fail(c, SXE_E_STATE, "image %u was never drawn", image_index);
+    const size_t need = (size_t)c->cfg.width * c->cfg.height * 4;
+    if (!img.h_color) SXE_HIP(c, hipHostMalloc(reinterpret_cast<void **>(&img.h_color), need, hipHostMallocDefault));
+    rc = sxe_sync(c);
+    if (rc) return rc;
+    SXE_HIP(c, hipMemcpyAsync(img.h_color, img.color.p, need, hipMemcpyDeviceToHost, c->stream));
+    SXE_HIP(c, hipStreamSynchronize(c->stream));
+    *rgba = img.h_color;
+    return SXE_OK;
 }
 
 int sxe_read_depth(sxe_ctx *c, uint32_t image_index, float *depth, size_t size_bytes)

@@ -371,6 +371,24 @@ def test_clipping_that_appears_after_quiet_frames(orc):
     assert_frames_equal(got_far, ref_far, what="cube back in front")
 
 
+def test_mapped_frame_equals_the_copied_one():
+    s = scenes.cube_scene(160, 120)
+    with api.HipDrawer(160, 120, n_images=2) as d:
+        with pytest.raises(api.SxeError):
+            d.map_color(0)  # nothing drawn yet
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.rotation_system(3, 0, 400.0)
+        d.draw(1)
+        first = d.map_color(0)
+        assert first.shape == (120, 160, 4) and not first.flags.writeable
+        assert np.array_equal(first, d.read_color(0))
+        second = d.map_color(1)
+        assert np.array_equal(second, d.read_color(1)) and not np.array_equal(first, second)
+        assert np.array_equal(first, d.read_color(0))  # mapping image 1 left image 0's copy alone
+
+
 def test_error_behaviour(orc):
     s = scenes.cube_scene(64, 64)
     with api.HipDrawer(64, 64) as d:

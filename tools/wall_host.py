@@ -11,13 +11,13 @@ w, h = s.size
 models = api.to_model(s.transforms)
 with api.HipDrawer(w, h, n_images=2) as d:
     d.update_scene(s); d.update_camera(s.camera)
-    for mode in ("device-resident", "update_uniforms per frame", "update_uniforms + read_color per frame"):
+    for mode in ("device-resident", "update_uniforms per frame", "update_uniforms + read_color per frame", "update_uniforms + map_color per frame"):
         for i in range(5):
             if mode == "device-resident":
                 d.rotation_system(3, i, 16.0)
             d.draw(i & 1)
         d.sync()
-        n = 100 if "read" not in mode else 30
+        n = 100 if "color" not in mode else 30
         t0 = time.perf_counter()
         for i in range(n):
             if mode == "device-resident":
@@ -28,6 +28,8 @@ with api.HipDrawer(w, h, n_images=2) as d:
             d.draw(i & 1)
             if "read" in mode:
                 d.read_color(i & 1)
+            if "map" in mode:
+                d.map_color(i & 1)
         d.sync()
         dt = (time.perf_counter() - t0) / n
         print("%-40s %.3f ms/frame  %.3e triangles/s" % (mode, 1e3 * dt, s.n_triangles / dt), flush=True)
