@@ -135,6 +135,8 @@ extern "C" {
     pub fn sxe_update_camera_matrices(ctx: *mut sxe_ctx, view: *const f32, proj: *const f32) -> c_int;
     pub fn sxe_draw(ctx: *mut sxe_ctx, image_index: u32) -> c_int;
     pub fn sxe_sync(ctx: *mut sxe_ctx) -> c_int;
+    /// draw + sync with every work buffer in the library's static device array (allocates nothing).
+    pub fn sxe_draw_noalloc(ctx: *mut sxe_ctx, image_index: u32) -> c_int;
     pub fn sxe_read_color(ctx: *mut sxe_ctx, image_index: u32, rgba: *mut u8, size_bytes: usize) -> c_int;
     pub fn sxe_map_color(ctx: *mut sxe_ctx, image_index: u32, rgba: *mut *const u8) -> c_int;
     pub fn sxe_read_depth(ctx: *mut sxe_ctx, image_index: u32, depth: *mut f32, size_bytes: usize) -> c_int;

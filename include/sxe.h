@@ -41,6 +41,7 @@ extern "C" {
 
 #define SXE_MAX_DIM 8192u          /* width and height limit (8K frames fit) */
 #define SXE_MAX_PRIMS (1u << 29)   /* triangles per frame */
+#define SXE_NOALLOC_SCRATCH_BYTES (32u << 20) /* static work memory of sxe_draw_noalloc, per GPU */
 
 typedef struct sxe_ctx sxe_ctx;
 
@@ -167,6 +168,19 @@ int sxe_update_camera_matrices(sxe_ctx *ctx, const float *view, const float *pro
 int sxe_draw(sxe_ctx *ctx, uint32_t image_index);
 /* The fence wait of src/renderer/drawer.rs:416-424.  Reports deferred device-side failures. */
 int sxe_sync(sxe_ctx *ctx);
+/* sxe_draw + sxe_sync for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs (the
+ * context's scene, uniforms and camera) and same output (image `image_index`) as sxe_draw, but every
+ * work buffer of the frame (per-object matrices, triangle records, bin tables, bins) lives in a
+ * static device array of SXE_NOALLOC_SCRATCH_BYTES that is part of the library's code object; the
+ * call makes no hipMalloc/hipFree and returns when the frame is finished.  Scenes whose work buffers
+ * do not fit fail with SXE_E_CAPACITY instead of growing anything: the array must hold about 124 bytes
+ * per submitted triangle (172 with a vertex-colour shading mode; objects count in steps of 256
+ * triangles), 72 bytes per screen tile and 4 bytes per (triangle, tile) bin entry, which is room for
+ * roughly 200,000 triangles.  No frame of sxe_draw may
+ * be in flight on the context (SXE_E_STATE; call sxe_sync first).  Every call on one GPU uses that
+ * GPU's one array, from whatever context or thread: calls that overlap on a GPU race. */
+int sxe_draw_noalloc(sxe_ctx *ctx, uint32_t image_index);
 
 /* ---- readback: stands in for Presenter::present (src/renderer/presenter.rs:415-430) ---- */
 int sxe_read_color(sxe_ctx *ctx, uint32_t image_index, uint8_t *rgba, size_t size_bytes);

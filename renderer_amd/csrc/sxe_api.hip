@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -76,6 +77,52 @@ struct FrameSlot {
     bool timed = false; // this frame's kernels are bracketed by events
     uint32_t image = 0;
 };
+
+// The device memory one frame works in besides its inputs and its images: per-object matrices,
+// triangle records, bin bookkeeping and the bins themselves.  sxe_draw takes it from the context's
+// own buffers, sxe_draw_noalloc from the library's static array.
+struct WorkBufs {
+    float *pvm = nullptr;
+    uint8_t *visible = nullptr;
+    uint32_t *blk_count = nullptr, *tile_counters = nullptr, *bins = nullptr, *bin_keys = nullptr, *bin_pos = nullptr,
+             *walk_list = nullptr;
+    uint4 *bin_pos4 = nullptr, *tile_launch = nullptr, *bin_start = nullptr;
+    RastRec *rast = nullptr;
+    WideRec *wide = nullptr;
+    ClipItem *clip_list = nullptr;
+    ShadeRec *shade = nullptr;
+    ColorRec *color = nullptr;
+    FrameCounters *counters = nullptr;
+    size_t fan_capacity = 0, bin_capacity = 0;
+    bool with_clip = true; // k_clip follows k_setup
+};
+
+} // namespace
+
+// Work memory of sxe_draw_noalloc: one array per GPU the library runs on, part of the loaded code
+// object, so no call ever allocates it.  In host code the name `scratch` is only a handle for
+// hipGetSymbolAddress; kernels and memsets get the per-device address kept in g_scratch_ptr.
+constexpr size_t kScratchBytes = SXE_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+
+std::mutex g_scratch_lock;
+unsigned char *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each device, set by sxe_create
+
+// With `device` current: looks up where this device holds its copy of `scratch`.
+hipError_t init_scratch(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    unsigned char *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
 
 } // namespace
 
@@ -394,20 +441,47 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     return SXE_OK;
 }
 
-ObjectArgs object_args(sxe_ctx *c, FrameSlot &fs)
+// The work buffers of an ordinary frame: the context's own, with the slot's per-object matrices.
+WorkBufs context_bufs(sxe_ctx *c, FrameSlot &fs)
+{
+    WorkBufs w;
+    w.pvm = fs.pvm.p;
+    w.visible = fs.visible.p;
+    w.blk_count = c->blk_count.p;
+    w.tile_counters = c->tile_counters.p;
+    w.bins = c->bins.p;
+    w.bin_keys = c->bin_keys.p;
+    w.bin_pos = c->bin_pos.p;
+    w.walk_list = c->walk_list.p;
+    w.bin_pos4 = c->bin_pos4.p;
+    w.tile_launch = c->tile_launch.p;
+    w.bin_start = c->bin_start.p;
+    w.rast = c->rast.p;
+    w.wide = c->wide.p;
+    w.clip_list = c->clip_list.p;
+    w.shade = c->shade.p;
+    w.color = c->color.p;
+    w.counters = c->counters.p;
+    w.fan_capacity = c->fan_capacity;
+    w.bin_capacity = c->bin_capacity;
+    w.with_clip = c->clip_enabled;
+    return w;
+}
+
+ObjectArgs object_args(sxe_ctx *c, const WorkBufs &w)
 {
     ObjectArgs oa{};
     oa.models = c->models.p;
     oa.pv = c->pv;
-    oa.pvm = fs.pvm.p;
+    oa.pvm = w.pvm;
     oa.meshes = c->meshes.p;
     oa.object_mesh = c->object_mesh.p;
-    oa.visible = fs.visible.p;
+    oa.visible = w.visible;
     oa.n = c->n_objects;
     oa.objects = 1;
-    oa.zero = c->tile_counters.p;
+    oa.zero = w.tile_counters;
     oa.n_zero = 0;
-    oa.counters = c->counters.p;
+    oa.counters = w.counters;
     oa.g = c->g;
     oa.transforms = c->transforms.p;
     oa.models_rw = c->models.p;
@@ -457,8 +531,9 @@ static bool frame_is_timed(const sxe_ctx *c, uint64_t frame)
     return (c->cfg.flags & SXE_FLAG_TIMING) != 0 && frame % c->timing_stride == 0;
 }
 
-// Enqueues the frame of slot `fs`.  A redraw (fresh == false) keeps the slot's per-object matrices.
-int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
+// Enqueues the frame of slot `fs` with the work buffers `w`.  A redraw (fresh == false) keeps the
+// per-object matrices in w.pvm.
+int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
 {
     Image &img = c->images[fs.image];
     const bool timing = fs.timed;
@@ -468,7 +543,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     const size_t ntc = std::max<uint32_t>(nt, 1);
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BEGIN], s));
     {
-        ObjectArgs oa = object_args(c, fs);
+        ObjectArgs oa = object_args(c, w);
         oa.objects = fresh ? 1u : 0u;
         if (fresh && c->rot_pending) {
             oa.rot_seed = c->rot_seed;
@@ -488,60 +563,60 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     sa.meshes = c->meshes.p;
     sa.insts = c->insts.p;
     sa.blocks = c->blocks.p;
-    sa.pvm = fs.pvm.p;
-    sa.visible = fs.visible.p;
+    sa.pvm = w.pvm;
+    sa.visible = w.visible;
     sa.n_blocks = c->n_blocks;
     sa.shading = c->cfg.shading;
     sa.debug = c->cfg.flags & kDebugMask;
     sa.g = c->g;
-    sa.blk_count = c->blk_count.p;
-    sa.tiles = reinterpret_cast<TileCtr *>(c->tile_counters.p);
-    sa.bin_pos = c->bin_pos.p;
-    sa.bin_pos4 = c->bin_pos4.p;
-    sa.rast = c->rast.p;
-    sa.wide = c->wide.p;
-    sa.shade = c->shade.p;
-    sa.color = c->color.p;
-    sa.fan_capacity = (uint32_t)c->fan_capacity;
-    sa.clip_list = c->clip_list.p;
-    sa.walk_list = c->walk_list.p;
-    sa.bin_keys = c->bin_keys.p;
-    sa.counters = c->counters.p;
-    sa.clip_off = c->clip_enabled ? 0u : 1u; // (k_setup must know whether k_clip follows)
+    sa.blk_count = w.blk_count;
+    sa.tiles = reinterpret_cast<TileCtr *>(w.tile_counters);
+    sa.bin_pos = w.bin_pos;
+    sa.bin_pos4 = w.bin_pos4;
+    sa.rast = w.rast;
+    sa.wide = w.wide;
+    sa.shade = w.shade;
+    sa.color = w.color;
+    sa.fan_capacity = (uint32_t)w.fan_capacity;
+    sa.clip_list = w.clip_list;
+    sa.walk_list = w.walk_list;
+    sa.bin_keys = w.bin_keys;
+    sa.counters = w.counters;
+    sa.clip_off = w.with_clip ? 0u : 1u; // (k_setup must know whether k_clip follows)
     SXE_HIP(c, launch_setup(sa, s));
-    if (c->clip_enabled) SXE_HIP(c, launch_clip(sa, s));
+    if (w.with_clip) SXE_HIP(c, launch_clip(sa, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SETUP], s));
 
     ScanArgs sc{};
-    sc.blk_count = c->blk_count.p;
+    sc.blk_count = w.blk_count;
     sc.n_blocks = c->n_blocks;
     sc.tiles = sa.tiles;
-    sc.bin_start = c->bin_start.p;
-    sc.tile_order = c->tile_counters.p + 9 * ntc;
+    sc.bin_start = w.bin_start;
+    sc.tile_order = w.tile_counters + 9 * ntc;
     sc.n_tiles = nt;
-    sc.bin_capacity = (uint32_t)std::min<size_t>(c->bin_capacity, 0xFFFFFFFFu);
-    sc.counters = c->counters.p;
+    sc.bin_capacity = (uint32_t)std::min<size_t>(w.bin_capacity, 0xFFFFFFFFu);
+    sc.counters = w.counters;
     SXE_HIP(c, launch_scan(sc, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SCAN], s));
 
     BinArgs ba{};
     ba.g = c->g;
-    ba.blk_count = c->blk_count.p;
+    ba.blk_count = w.blk_count;
     ba.n_blocks = c->n_blocks;
     ba.walk_blocks = 256; // 1024 waves share the list of late entries, however long it is
-    ba.rast = c->rast.p;
-    ba.wide = c->wide.p;
-    ba.bin_keys = c->bin_keys.p;
-    ba.bin_pos = c->bin_pos.p;
-    ba.bin_pos4 = c->bin_pos4.p;
+    ba.rast = w.rast;
+    ba.wide = w.wide;
+    ba.bin_keys = w.bin_keys;
+    ba.bin_pos = w.bin_pos;
+    ba.bin_pos4 = w.bin_pos4;
     ba.tiles = sa.tiles;
-    ba.bin_start = reinterpret_cast<const uint32_t *>(c->bin_start.p);
-    ba.late_fill = c->tile_counters.p + 8 * ntc;
+    ba.bin_start = reinterpret_cast<const uint32_t *>(w.bin_start);
+    ba.late_fill = w.tile_counters + 8 * ntc;
     ba.tile_order = sc.tile_order;
-    ba.tile_launch = c->tile_launch.p;
-    ba.bins = c->bins.p;
-    ba.counters = c->counters.p;
-    ba.walk_list = c->walk_list.p;
+    ba.tile_launch = w.tile_launch;
+    ba.bins = w.bins;
+    ba.counters = w.counters;
+    ba.walk_list = w.walk_list;
     // the binning switches leave the bins unusable: only honoured when the tile kernel skips them
     ba.debug = (c->cfg.flags & kDebugSkipRaster) ? (c->cfg.flags & kDebugMask) : 0u;
     SXE_HIP(c, launch_bin(ba, s));
@@ -549,13 +624,13 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
 
     RasterArgs ra{};
     ra.g = c->g;
-    ra.tile_launch = c->tile_launch.p;
-    ra.bins = c->bins.p;
-    ra.rast = c->rast.p;
-    ra.wide = c->wide.p;
-    ra.shade = c->shade.p;
-    ra.color = c->color.p;
-    ra.counters = c->counters.p;
+    ra.tile_launch = w.tile_launch;
+    ra.bins = w.bins;
+    ra.rast = w.rast;
+    ra.wide = w.wide;
+    ra.shade = w.shade;
+    ra.color = w.color;
+    ra.counters = w.counters;
     ra.texels = c->texels.p;
     ra.textures = c->textab.p;
     ra.n_textures = c->n_textures;
@@ -574,7 +649,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh)
     SXE_HIP(c, launch_raster_shade(ra, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_RASTER], s));
 
-    if (!direct) SXE_HIP(c, hipMemcpyAsync(fs.h_counters, c->counters.p, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
+    if (!direct) SXE_HIP(c, hipMemcpyAsync(fs.h_counters, w.counters, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
     SXE_HIP(c, hipEventRecord(fs.done, s));
     img.drawn = true;
     fs.pending = true;
@@ -604,6 +679,56 @@ int grow_for(sxe_ctx *c, const FrameSlot &fs)
     return SXE_OK;
 }
 
+void record_stats(sxe_ctx *c, const FrameCounters &k)
+{
+    c->stats.prims = c->n_prims;
+    c->stats.records = k.total_records;
+    c->stats.bin_entries = k.total_pairs;
+    c->stats.tiles = c->g.n_tiles;
+    c->stats.instance_vertices = c->n_inst_vertices;
+    c->stats.objects = c->n_objects;
+    c->stats.tile_size = kTile;
+    c->stats.redraws = c->redraws;
+}
+
+// Cuts the work buffers of the context's scene out of this device's static array.  The bins get
+// what the fixed-size parts leave.  False: the scene is too large for the array.
+bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fixed_bytes)
+{
+    constexpr size_t kNoAllocFan = 4096; // fan records of clipped triangles, and clip list entries
+    const size_t slots = (size_t)c->n_blocks * kSetupThreads, recs = slots + kNoAllocFan;
+    const size_t ntc = std::max<uint32_t>(c->g.n_tiles, 1), nobj = std::max<uint32_t>(c->n_objects, 1);
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base + at;
+        at += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    w.counters = reinterpret_cast<FrameCounters *>(take(sizeof(FrameCounters)));
+    w.blk_count = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(c->n_blocks, 1)));
+    w.tile_counters = reinterpret_cast<uint32_t *>(take(4 * 10 * ntc));
+    w.tile_launch = reinterpret_cast<uint4 *>(take(16 * ntc));
+    w.bin_start = reinterpret_cast<uint4 *>(take(16 * ntc));
+    w.pvm = reinterpret_cast<float *>(take(64 * nobj));
+    w.visible = reinterpret_cast<uint8_t *>(take(nobj));
+    w.bin_keys = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(slots, 1)));
+    w.bin_pos = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(slots, 1)));
+    w.bin_pos4 = reinterpret_cast<uint4 *>(take(16 * std::max<size_t>(slots, 1)));
+    w.walk_list = reinterpret_cast<uint32_t *>(take(4 * recs));
+    w.rast = reinterpret_cast<RastRec *>(take(sizeof(RastRec) * recs));
+    w.wide = reinterpret_cast<WideRec *>(take(sizeof(WideRec) * recs));
+    w.shade = reinterpret_cast<ShadeRec *>(take(sizeof(ShadeRec) * recs));
+    w.color = c->cfg.shading != SXE_SHADE_TEXTURE ? reinterpret_cast<ColorRec *>(take(sizeof(ColorRec) * recs)) : nullptr;
+    w.clip_list = reinterpret_cast<ClipItem *>(take(sizeof(ClipItem) * kNoAllocFan));
+    fixed_bytes = at;
+    if (at + 4 * 4096 > kScratchBytes) return false;
+    w.bins = reinterpret_cast<uint32_t *>(base + at);
+    w.bin_capacity = (kScratchBytes - at) / 4;
+    w.fan_capacity = kNoAllocFan;
+    w.with_clip = true; // always: a frame that finds a triangle to clip cannot be drawn again here
+    return true;
+}
+
 // Takes the result of the oldest frame in flight: waits for it, and if one of its work buffers
 // was too small, grows the buffers and renders it again -- and after it every younger frame in
 // flight, in order, because they may share its image or have overflowed as well.
@@ -620,7 +745,7 @@ int retire_oldest(sxe_ctx *c)
                 int rc = grow_for(c, r);
                 if (rc) return rc;
                 c->redraws++;
-                rc = enqueue_frame(c, r, false);
+                rc = enqueue_frame(c, r, false, context_bufs(c, r));
                 if (rc) return rc;
                 SXE_HIP(c, hipStreamSynchronize(c->stream));
             }
@@ -641,14 +766,7 @@ int retire_oldest(sxe_ctx *c)
     } else if (c->clip_enabled && ++c->clip_quiet >= kClipQuiet) {
         c->clip_enabled = false;
     }
-    c->stats.prims = c->n_prims;
-    c->stats.records = k.total_records;
-    c->stats.bin_entries = k.total_pairs;
-    c->stats.tiles = c->g.n_tiles;
-    c->stats.instance_vertices = c->n_inst_vertices;
-    c->stats.objects = c->n_objects;
-    c->stats.tile_size = kTile;
-    c->stats.redraws = c->redraws;
+    record_stats(c, k);
     if ((c->cfg.flags & kDebugSkipAtomic) && getenv("SXE_DEBUG_COUNTERS"))
         fprintf(stderr, "[sxe] wide entries %u, wide box pixels %u, lane box pixels %u, clip %u fans %u\n", k.pad[0], k.pad[1],
                 k.pad[2], k.clip_count, k.fan_records);
@@ -751,8 +869,15 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         return fail(nullptr, SXE_E_DEVICE, "no HIP device available (%s); this library has no CPU path",
                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (k.device < 0 || k.device >= ndev) return fail(nullptr, SXE_E_INVALID, "device %d not in 0..%d", k.device, ndev - 1);
+    if (k.device >= kMaxDevices) return fail(nullptr, SXE_E_CAPACITY, "device ordinals above %d are not supported", kMaxDevices - 1);
     e = hipSetDevice(k.device);
     if (e != hipSuccess) return fail(nullptr, SXE_E_DEVICE, "hipSetDevice failed: %s", hipGetErrorString(e));
+    // per-device state of the library: the tile kernel's constant tables and the address of the
+    // static work array of sxe_draw_noalloc
+    if ((e = init_device_tables(k.device)) != hipSuccess)
+        return fail(nullptr, SXE_E_DEVICE, "uploading the colour tables failed: %s", hipGetErrorString(e));
+    if ((e = init_scratch(k.device)) != hipSuccess)
+        return fail(nullptr, SXE_E_DEVICE, "hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
 
     sxe_ctx *c = new (std::nothrow) sxe_ctx();
     if (!c) return fail(nullptr, SXE_E_DEVICE, "out of host memory");
@@ -1002,7 +1127,7 @@ int sxe_draw(sxe_ctx *c, uint32_t image_index)
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
     fs.image = image_index;
     fs.timed = frame_is_timed(c, c->frames_enqueued);
-    rc = enqueue_frame(c, fs, true);
+    rc = enqueue_frame(c, fs, true, context_bufs(c, fs));
     if (rc) return rc;
     c->frames_enqueued++;
     return SXE_OK;
@@ -1017,6 +1142,51 @@ int sxe_sync(sxe_ctx *c)
         if (rc) return rc;
     }
     SXE_HIP(c, hipStreamSynchronize(c->stream));
+    return SXE_OK;
+}
+
+int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "draw before update_drawables");
+    if (!c->have_camera) return fail(c, SXE_E_STATE, "draw before update_camera");
+    if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
+    // taking a frame of sxe_draw out of flight may have to grow its buffers: not from here
+    if (c->frames_retired != c->frames_enqueued)
+        return fail(c, SXE_E_STATE, "frames of sxe_draw are in flight: call sxe_sync before sxe_draw_noalloc");
+    unsigned char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(g_scratch_lock);
+        base = g_scratch_ptr[c->cfg.device];
+    }
+    if (!base) return fail(c, SXE_E_DEVICE, "the static work array was not located on device %d", c->cfg.device);
+    WorkBufs w;
+    size_t fixed = 0;
+    if (!static_bufs(c, base, w, fixed))
+        return fail(c, SXE_E_CAPACITY,
+                    "scene needs %zu bytes of record and table space, the static work array holds %zu "
+                    "(%u setup work items of 256 triangles, %u tiles, %u objects)",
+                    fixed, kScratchBytes, c->n_blocks, c->g.n_tiles, c->n_objects);
+    // Nothing of an earlier call's contents is relied upon: the frame's first kernel clears the
+    // counters and per-tile tables, and every other table entry is written before it is read.
+    FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+    fs.image = image_index;
+    fs.timed = false;
+    rc = enqueue_frame(c, fs, true, w);
+    if (rc) return rc;
+    SXE_HIP(c, hipEventSynchronize(fs.done));
+    fs.pending = false; // (the slot was only borrowed: the frame counts of sxe_draw do not move)
+    const FrameCounters &k = *fs.h_counters;
+    if (k.overflow) {
+        c->images[image_index].drawn = false;
+        if (k.overflow & kOverflowBins)
+            return fail(c, SXE_E_CAPACITY, "frame needs %u bin entries, the static work array has room for %zu", k.total_pairs,
+                        w.bin_capacity);
+        return fail(c, SXE_E_CAPACITY, "frame clips %u triangles into %u fan triangles, the static work array has room for %zu",
+                    k.clip_count, k.fan_records, w.fan_capacity);
+    }
+    record_stats(c, k);
     return SXE_OK;
 }
 
@@ -1091,7 +1261,7 @@ int sxe_read_clip_positions(sxe_ctx *c, float *clip, size_t size_bytes)
     if (rc) return rc;
     SXE_HIP(c, c->clip.reserve(std::max<size_t>(c->n_inst_vertices, 1)));
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
-    SXE_HIP(c, launch_object(object_args(c, fs), c->stream));
+    SXE_HIP(c, launch_object(object_args(c, context_bufs(c, fs)), c->stream));
     SXE_HIP(c, launch_vertex(c->pos_x.p, c->pos_y.p, c->pos_z.p, c->meshes.p, c->vblocks.p, c->n_vblocks, fs.pvm.p,
                              c->clip.p, c->stream));
     SXE_HIP(c, hipStreamSynchronize(c->stream));

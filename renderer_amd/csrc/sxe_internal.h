@@ -258,7 +258,11 @@ struct RasterArgs {
     uint32_t debug;
 };
 
-// Launchers (defined in sxe_kernels.hip). All enqueue on `s` and return the launch status.
+constexpr int kMaxDevices = 64; // device ordinals the library keeps per-device state for
+// Constant tables of the tile kernel (sRGB decode and encode): once per device, from sxe_create.
+hipError_t init_device_tables(int device);
+
+// Launchers (defined in sxe_geometry.hip and sxe_raster.hip). All enqueue on `s` and return the launch status.
 hipError_t launch_object(const ObjectArgs &a, hipStream_t s);
 hipError_t launch_transform_to_model(const sxe_transform *t, float *models, uint32_t n, hipStream_t s);
 hipError_t launch_rotation_system(sxe_transform *t, float *models, uint32_t n, uint64_t seed,

@@ -14,11 +14,12 @@
 #include "sxe_device.h"
 #include "sxe_srgb_tables.h"
 
+#include <mutex>
+
 namespace sxe {
 
 __constant__ float c_srgb_decode[256];
 __constant__ float c_unorm8[256];
-static bool g_tables_ready[64] = {};
 
 // Linear value -> sRGB8 code = number of encode thresholds <= x.  The floats from 2^-13 (below the
 // first threshold) to 1.0 are cut into buckets that share sign, exponent and seven mantissa bits;
@@ -83,16 +84,21 @@ static uint32_t srgb_encode_host(const uint32_t *enc, float x)
     return (e >> 24) + (((uint32_t)bits & 0xFFFFu) >= (e & 0x1FFFFu) ? 1u : 0u);
 }
 
-static hipError_t ensure_tables()
+// Uploads the constant tables of the tile kernel to `device` (which must be current).  Called by
+// sxe_create, once per device however many threads create contexts at the same time; the launch
+// path does not check again.
+hipError_t init_device_tables(int device)
 {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 64 && g_tables_ready[dev]) return hipSuccess;
+    static std::mutex lock;
+    static bool ready[kMaxDevices] = {};
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(lock);
+    if (ready[device]) return hipSuccess;
+    hipError_t e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_srgb_decode), SXE_SRGB_DECODE, sizeof(float) * 256)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_unorm8), SXE_UNORM8, sizeof(float) * 256)) != hipSuccess) return e;
     if ((e = upload_encode_table()) != hipSuccess) return e;
-    if (dev < 64) g_tables_ready[dev] = true;
+    ready[device] = true;
     return hipSuccess;
 }
 
@@ -686,8 +692,6 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
 
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 {
-    hipError_t e = ensure_tables();
-    if (e != hipSuccess) return e;
     if (a.g.n_tiles == 0) return hipSuccess;
     if (a.out_prim)
         hipLaunchKernelGGL(k_raster_shade<true>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
