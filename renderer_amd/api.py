@@ -216,6 +216,9 @@ class HipDrawer:
                 raise SxeError(E_INVALID, "empty scissor")
         cfg.shading = shading
         cfg.flags = (FLAG_WRITE_COVERAGE if coverage else 0) | (FLAG_TIMING if timing else 0) | debug_flags
+        if debug_flags:
+            # development switches (tools/ only): the library refuses them without this
+            os.environ.setdefault("SXE_DEVELOPMENT", "1")
         if clear is not None:
             cfg.clear = (C.c_float * 4)(*clear)
         if fov_deg is not None:

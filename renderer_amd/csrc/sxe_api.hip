@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -134,6 +135,8 @@ struct sxe_ctx {
 
     // scene
     bool have_scene = false, have_camera = false;
+    int32_t scene_max_texture = -1; // largest texture index the uploaded scene samples
+    bool scene_lost_textures = false; // the texture table was replaced by one that lacks some of them
     uint32_t n_objects = 0, n_draws = 0, n_blocks = 0, n_vblocks = 0, n_meshes = 0, n_textures = 0;
     uint64_t n_prims = 0, n_inst_vertices = 0;
     DevBuf<sxe_vertex> vertices;
@@ -339,6 +342,9 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
         order.push_back(o);
     }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ho[a].texture < ho[b].texture; });
+    int32_t max_texture = -1;
+    if (need_tex)
+        for (uint32_t o : order) max_texture = std::max(max_texture, ho[o].texture);
 
     // vertex range touched by every run of 256 triangles of every mesh (mesh-local indices)
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ranges(hm.size());
@@ -426,6 +432,8 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     c->n_inst_vertices = inst_vtx;
     c->have_transforms = true;
     c->have_scene = true;
+    c->scene_max_texture = max_texture;
+    c->scene_lost_textures = false;
     c->clip_enabled = true;
     c->clip_quiet = 0;
 
@@ -738,6 +746,14 @@ int retire_oldest(sxe_ctx *c)
     SXE_HIP(c, hipEventSynchronize(fs.done));
     if (fs.h_counters->overflow) {
         SXE_HIP(c, hipStreamSynchronize(c->stream));
+        bool hopeless = false; // a frame in flight that no regrowth can hold
+        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f)
+            hopeless = hopeless || (c->slots[f % kFrameSlots].h_counters->overflow & kOverflowPairs);
+        if (hopeless) {
+            for (FrameSlot &x : c->slots) x.pending = false;
+            c->frames_retired = c->frames_enqueued;
+            return fail(c, SXE_E_CAPACITY, "frame has more than 2^32 - 1 (triangle, tile) bin entries");
+        }
         for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
             FrameSlot &r = c->slots[f % kFrameSlots];
             // the oldest frame overflowed; the younger ones are drawn again after it in any case
@@ -860,6 +876,12 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if (k.scissor_y0 == 0 && k.scissor_y1 == 0) k.scissor_y1 = k.height;
     if (k.scissor_y0 > k.scissor_y1 || k.scissor_y1 > k.height)
         return fail(nullptr, SXE_E_INVALID, "scissor rows [%u,%u) outside the frame", k.scissor_y0, k.scissor_y1);
+    // bits 26-31 select development builds of the kernels whose images are wrong on purpose
+    if ((k.flags & kDebugMask) && !(getenv("SXE_DEVELOPMENT") && getenv("SXE_DEVELOPMENT")[0] == '1'))
+        return fail(nullptr, SXE_E_INVALID, "flags 0x%x: bits 26-31 are development switches (set SXE_DEVELOPMENT=1 to use them)",
+                    k.flags & kDebugMask);
+    if (k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask))
+        return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask));
     if (k.n_images == 0) k.n_images = 1;
     if (k.n_images > 16) return fail(nullptr, SXE_E_CAPACITY, "at most 16 images");
 
@@ -995,6 +1017,12 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
                              4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice));
     if (n) SXE_HIP(c, hipMemcpy(c->textab.p, tab.data(), n * sizeof(TexDev), hipMemcpyHostToDevice));
     c->n_textures = n;
+    // The scene's texture indices were checked against the table of its upload.  A table that no
+    // longer holds all of them must not be sampled with them: the scene has to be uploaded again.
+    if (c->have_scene && c->scene_max_texture >= (int32_t)n) {
+        c->have_scene = false;
+        c->scene_lost_textures = true;
+    }
     return SXE_OK;
 }
 
@@ -1116,7 +1144,10 @@ int sxe_draw(sxe_ctx *c, uint32_t image_index)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
-    if (!c->have_scene) return fail(c, SXE_E_STATE, "draw before update_drawables");
+    if (!c->have_scene)
+        return fail(c, SXE_E_STATE, c->scene_lost_textures ? "the texture table was replaced by one without all textures the scene "
+                                                            "uses: call update_drawables again before draw"
+                                                          : "draw before update_drawables");
     if (!c->have_camera) return fail(c, SXE_E_STATE, "draw before update_camera");
     if (image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "image index %u out of range", image_index);
     // at most kFrameSlots frames are in flight: take the oldest one's result when all slots are used

@@ -624,8 +624,12 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
 }
 
 // (six resident waves per SIMD matter more to this kernel than the last few registers)
+// DEV: built with the development switches of SetupArgs::debug; the ordinary build has none of
+// their tests in its code.
+template <bool DEV>
 __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
 {
+    if (!DEV) a.debug = 0u;
     // one work item per workgroup (several in a loop measured slower, and a loop keeps per-thread
     // addresses alive across it, which this kernel has no registers for)
     __shared__ SetupShared sh;
@@ -701,6 +705,15 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
+__device__ inline unsigned long long wave_inclusive_scan64(unsigned long long v, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
 constexpr int kOrderClasses = 128;
 __device__ inline uint32_t order_class(uint32_t count) { return min((count + 15u) >> 4, (uint32_t)kOrderClasses - 1u); }
 
@@ -727,13 +740,16 @@ __device__ inline uint32_t tile_cost(const ScanArgs &a, uint32_t i)
 // between workgroups.
 constexpr uint32_t kScanChunk = 8192;
 
-__device__ inline uint32_t block_sum(uint32_t v, uint32_t *s_part, int lane, int wave)
+// Sums are kept in 64 bits: a frame inside the stated limits can hold more than 2^32 (triangle,
+// tile) pairs (a few ten thousand screen-filling triangles on an 8K frame), and a total that wrapped
+// would pass the capacity check.
+__device__ inline unsigned long long block_sum(unsigned long long v, unsigned long long *s_part, int lane, int wave)
 {
     for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
     __syncthreads(); // s_part may still be read from an earlier call
     if (lane == 0) s_part[wave] = v;
     __syncthreads();
-    uint32_t tot = 0;
+    unsigned long long tot = 0;
     for (int w = 0; w < 16; ++w) tot += s_part[w];
     return tot;
 }
@@ -758,7 +774,7 @@ __device__ inline uint32_t class_take(uint32_t *counter, uint32_t cls, bool on, 
 
 __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 {
-    __shared__ uint32_t s_part[16];
+    __shared__ unsigned long long s_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t last_tile = max(a.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
     const uint32_t chunks = max((a.n_tiles + kScanChunk - 1u) / kScanChunk, 1u);
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
             for (int k = 0; k < 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
         if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
-        const uint32_t tot = block_sum(sum, s_part, lane, wave);
+        const uint32_t tot = (uint32_t)block_sum(sum, s_part, lane, wave); // (at most 256 per work item, 2^23 work items)
         if (tid == 0) a.counters->total_records = tot;
         return;
     }
@@ -833,7 +849,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 #pragma unroll
     for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + 1024u * k, last_tile)];
     // what the bins of the earlier chunks take
-    uint32_t earlier = 0;
+    unsigned long long earlier = 0;
     for (uint32_t i = tid; i < base; i += 8192) { // (base is a multiple of 8192: no bounds to check)
         uint32_t sz[8];
 #pragma unroll
@@ -841,27 +857,29 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
 #pragma unroll
         for (int k = 0; k < 8; ++k) earlier += sz[k];
     }
-    const uint32_t carry = block_sum(earlier, s_part, lane, wave);
+    const unsigned long long carry = block_sum(earlier, s_part, lane, wave);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s_size[tid + 1024 * k] = (base + (uint32_t)tid + 1024u * k < a.n_tiles) ? bin_size(mine[k]) : 0u;
     __syncthreads();
-    uint32_t v[8], sum = 0;
+    uint32_t v[8];
+    unsigned long long sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         v[k] = s_size[8 * tid + k];
         sum += v[k];
     }
-    const uint32_t incl = wave_inclusive_scan(sum, lane);
+    const unsigned long long incl = wave_inclusive_scan64(sum, lane);
     __syncthreads(); // (block_sum's s_part has been read by everybody)
     if (lane == 63) s_part[wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0, tot = 0;
+    unsigned long long wbase = 0, tot = 0;
     for (int w = 0; w < 16; ++w) {
-        const uint32_t p = s_part[w];
+        const unsigned long long p = s_part[w];
         if (w < wave) wbase += p;
         tot += p;
     }
-    uint32_t run = carry + wbase + incl - sum;
+    // (offsets are used only when the total fits the bin array, which holds fewer than 2^32 entries)
+    uint32_t run = (uint32_t)(carry + wbase + incl - sum);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         s_size[8 * tid + k] = run; // the tile's offset from here on
@@ -875,9 +893,10 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         if (i < a.n_tiles) a.bin_start[i] = make_uint4(off, off + c0, off + c0 + c1, off + c0 + c1 + c2);
     }
     if (tid == 0 && chunk + 1u == chunks) {
-        const uint32_t total = carry + tot;
-        a.counters->total_pairs = total;
+        const unsigned long long total = carry + tot;
+        a.counters->total_pairs = (uint32_t)min(total, 0xFFFFFFFFull);
         if (total > a.bin_capacity) atomicOr(&a.counters->overflow, kOverflowBins);
+        if (total > 0xFFFFFFFFull) atomicOr(&a.counters->overflow, kOverflowPairs); // no bin array can hold this frame
     }
 }
 
@@ -1009,8 +1028,10 @@ __device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint3
 // workgroups past the last work item take the listed triangles that span more than four tiles and
 // the fan triangles of clipped primitives.
 constexpr uint32_t kWalkChunk = 16;
+template <bool DEV>
 __global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
 {
+    if (!DEV) a.debug = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;
     const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
@@ -1136,7 +1157,10 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_setup, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+    if (a.debug)
+        hipLaunchKernelGGL(k_setup<true>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_setup<false>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1161,7 +1185,10 @@ hipError_t launch_bin(const BinArgs &a, hipStream_t s)
     const uint32_t filing = (a.n_blocks + 3u) / 4u + a.walk_blocks, listing = (a.g.n_tiles + kSetupThreads - 1u) / kSetupThreads;
     const uint32_t groups = filing > listing ? filing : listing;
     if (groups == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bin, dim3(groups), dim3(kSetupThreads), 0, s, a);
+    if (a.debug)
+        hipLaunchKernelGGL(k_bin<true>, dim3(groups), dim3(kSetupThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_bin<false>, dim3(groups), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 

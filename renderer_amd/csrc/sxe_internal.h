@@ -32,6 +32,7 @@ constexpr uint32_t kDebugMask = 63u << 26;
 // overflow bits of FrameCounters::overflow
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
 constexpr uint32_t kOverflowNoClip = 4u; // a triangle needs clipping in a frame enqueued without the clip kernel
+constexpr uint32_t kOverflowPairs = 8u;  // more than 2^32 - 1 (triangle, tile) pairs: beyond any bin array
 
 struct MeshDev {
     uint32_t vtx_base, n_vtx, idx_base, n_tri;

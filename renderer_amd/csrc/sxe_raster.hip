@@ -331,9 +331,15 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
 
 // (seven resident workgroups per compute unit: 72 registers and at most 22 KB of LDS, which is
 // handed out in 1 KB pieces; eight would need spills)
-template <bool COVERAGE>
+// COVERAGE: the frame keeps a primitive-id image.  DEV: built with the development switches of
+// RasterArgs::debug and the per-tile clock stamps; the ordinary build has none of their tests.
+template <bool COVERAGE, bool DEV>
 __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_raster_shade(RasterArgs a)
 {
+    if (!DEV) {
+        a.debug = 0u;
+        a.tile_times = nullptr;
+    }
     __shared__ unsigned long long vis[kTilePixels]; // (depth bits << 32) | order, per pixel
     __shared__ __attribute__((aligned(16))) uint32_t s_enc[kEncPadded];
     __shared__ float s_dec[256];
@@ -693,10 +699,16 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 {
     if (a.g.n_tiles == 0) return hipSuccess;
-    if (a.out_prim)
-        hipLaunchKernelGGL(k_raster_shade<true>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
+    const bool dev = a.debug != 0u || a.tile_times != nullptr;
+    const dim3 grid(a.g.n_tiles), block(kRasterThreads);
+    if (a.out_prim && dev)
+        hipLaunchKernelGGL((k_raster_shade<true, true>), grid, block, 0, s, a);
+    else if (a.out_prim)
+        hipLaunchKernelGGL((k_raster_shade<true, false>), grid, block, 0, s, a);
+    else if (dev)
+        hipLaunchKernelGGL((k_raster_shade<false, true>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL(k_raster_shade<false>, dim3(a.g.n_tiles), dim3(kRasterThreads), 0, s, a);
+        hipLaunchKernelGGL((k_raster_shade<false, false>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

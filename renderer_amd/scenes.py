@@ -166,6 +166,32 @@ def sphere_field_scene(n, seed, box_xy, z_range, width, height, n_textures=4, te
                               size=(width, height), name=name)
 
 
+def mixed_scene(n=40, seed=21, width=640, height=360):
+    """Two different meshes (the cube and the grid sphere) spread over three texture groups, some
+    objects with `rendered` false (src/components/mesh.rs:8): the draw order the reference derives
+    (texture groups ascending, drawable order inside a group, src/renderer/drawer.rs:313-347,481-487)
+    then differs from the caller's order, and the meshes have different index counts."""
+    cv, ci = cube_mesh()
+    sv, si = grid_sphere_mesh()
+    vertices = np.concatenate([cv, sv])
+    indices = np.concatenate([ci, si])
+    meshes = np.array([(0, len(cv), 0, len(ci)), (len(cv), len(sv), len(ci), len(si))], dtype=MESH)
+    rng = np.random.default_rng(seed)
+    t = np.ascontiguousarray(api.identity_transforms(1).repeat(n))
+    t["position"][:, 0:2] = rng.uniform(-6.0, 6.0, size=(n, 2))
+    t["position"][:, 2] = rng.uniform(-18.0, -4.0, size=n)
+    t["scale"] = rng.uniform(0.6, 2.0, size=(n, 1)).astype(np.float32)
+    euler = rng.uniform(0.0, 360.0, size=(n, 3)).astype(np.float32)
+    for i in range(n):
+        api.rotate(t, i, float(euler[i, 0]), float(euler[i, 1]), float(euler[i, 2]))
+    objects = np.zeros(n, dtype=OBJECT)
+    objects["mesh"] = rng.integers(0, 2, size=n)
+    objects["texture"] = rng.integers(0, 3, size=n)
+    objects["rendered"] = (rng.random(n) > 0.25).astype(np.uint32)
+    return Scene(vertices, indices, meshes, objects, t, [checker_texture(128, 40 + k) for k in range(3)],
+                 size=(width, height), name="mixed-meshes-groups")
+
+
 def config_scene(cfg, scale=1.0):
     """The benchmark configurations. `scale` < 1 shrinks object count and frame size together
     for parity tests the CPU oracle can finish in seconds."""

@@ -481,3 +481,147 @@ def test_full_size_config3_against_oracle(orc):
         d.draw(0)
         band = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
     assert_frames_equal(band, ref, rows=(y0, y1), what="config 3 band 2/4")
+
+
+# ---- the benchmark configurations at their full sizes ----
+
+def test_full_size_config2_against_oracle(orc):
+    """Config 2: 100 spheres = 102,400 triangles at 1920x1080."""
+    s = scenes.config_scene(2)
+    assert s.size == (1920, 1080) and s.n_triangles == 102400
+    ref = render_oracle(orc, s, threads=16)
+    got = render_hip(s)
+    assert (ref["prim"] != 0xFFFFFFFF).sum() > 100000
+    assert_frames_equal(got, ref, what="config 2 full size")
+
+
+def test_full_size_config4_single_context_and_eight_bands(orc):
+    """Config 4: the 10.24 M-triangle scene at 7680x4320 (32,400 tiles: four chunks of bin offsets,
+    33 M pixels), in one context and as the eight sort-first bands of shard.band_rows."""
+    from renderer_amd import shard
+    s = scenes.config_scene(4)
+    w, h = s.size
+    assert (w, h) == (7680, 4320)
+    ref = orc.render(s, orc.to_model(s.transforms), *orc.camera(s.camera, w, h), w, h, threads=16)
+    with api.HipDrawer(w, h, n_images=1, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        assert d.stats()["tiles"] == 240 * 135 and d.stats()["prims"] == 10240000
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+    assert_frames_equal(got, ref, what="config 4 single context")
+    del got
+    covered = np.zeros(h, bool)
+    for rank in range(8):
+        y0, y1 = shard.band_rows(h, 8, rank)
+        with api.HipDrawer(w, h, n_images=1, coverage=True, scissor=(y0, y1)) as d:
+            d.update_scene(s)
+            d.update_camera(s.camera)
+            d.draw(0)
+            d.sync()
+            band = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+        assert_frames_equal(band, ref, rows=(y0, y1), what="config 4 band %d/8" % rank)
+        assert not covered[y0:y1].any()
+        covered[y0:y1] = True
+    assert covered.all()
+
+
+def test_full_size_config5_views(orc):
+    """Config 5: the 100-sphere scene, 512x512 views from cameras on a sphere around it; ten of the
+    4096 views (every rank's first one for eight ranks, and the last two), frames in flight."""
+    from renderer_amd import shard
+    s = scenes.config_scene(5)
+    w, h = s.size
+    assert (w, h) == (512, 512) and len(s.objects) == 100
+    cams = scenes.orbit_cameras(4096, 5, radius=60.0, target=(0.0, 0.0, -22.5))
+    views = [shard.views_for_rank(4096, 8, r)[0] for r in range(8)] + [4094, 4095]
+    models = orc.to_model(s.transforms)
+    with api.HipDrawer(w, h, n_images=len(views), coverage=True) as d:
+        d.update_scene(s)
+        for k, v in enumerate(views):
+            d.update_camera(cams[v:v + 1])
+            d.draw(k)
+        d.sync()
+        seen = 0
+        for k, v in enumerate(views):
+            view, proj = orc.camera(cams[v:v + 1], w, h)
+            ref = orc.render(s, models, view, proj, w, h)
+            got = {"color": d.read_color(k), "depth": d.read_depth(k), "prim": d.read_coverage(k)}
+            assert_frames_equal(got, ref, what="config 5 view %d" % v)
+            seen += int((ref["prim"] != 0xFFFFFFFF).sum())
+    assert seen > 10000
+
+
+def test_unrendered_objects_and_two_meshes_over_three_texture_groups(orc):
+    """update_drawables' draw list (src/renderer/drawer.rs:313-347,481-487): objects with
+    `rendered` false are left out, the rest is drawn by texture group; meshes of different sizes."""
+    s = scenes.mixed_scene()
+    assert set(np.unique(s.objects["texture"])) == {0, 1, 2} and set(np.unique(s.objects["mesh"])) == {0, 1}
+    assert 0 < (s.objects["rendered"] == 0).sum() < len(s.objects)
+    ref = render_oracle(orc, s)
+    assert ref["stats"]["prims"] == s.n_triangles
+    got = render_hip(s, use_drawables=True)
+    assert_frames_equal(got, ref, what="mixed scene via update_drawables")
+    got = render_hip(s)
+    assert_frames_equal(got, ref, what="mixed scene via update_instances")
+    # primitive ids follow the draw order: the first drawn object is the first rendered one of texture 0
+    everything = scenes.mixed_scene()
+    everything.objects["rendered"] = 1
+    full = render_oracle(orc, everything)
+    assert not np.array_equal(full["color"], ref["color"])
+
+
+# ---- limits ----
+
+def test_texture_table_that_shrinks_under_a_scene_is_refused(orc):
+    s = scenes.reference_demo_scene(width=256, height=192)  # samples textures 0..2
+    with api.HipDrawer(256, 192) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        before = d.read_color(0)
+        d.set_textures(s.textures[:1])  # the scene still refers to textures 1 and 2
+        with pytest.raises(api.SxeError) as e:
+            d.draw(1)
+        assert e.value.code == api.E_STATE and "texture table" in str(e.value)
+        with pytest.raises(api.SxeError):
+            d.draw_noalloc(1)
+        d.set_textures([])
+        with pytest.raises(api.SxeError) as e:
+            d.draw(1)
+        assert e.value.code == api.E_STATE
+        d.update_scene(s)  # uploads table and scene together again
+        d.draw(1)
+        assert np.array_equal(d.read_color(1), before)
+        d.set_textures(s.textures + s.textures[:1])  # a larger table keeps the scene valid
+        d.draw(0)
+        assert np.array_equal(d.read_color(0), before)
+
+
+def test_more_than_2_to_the_32_bin_entries_is_a_capacity_error():
+    """66,000 screen-filling triangles on an 8192x8192 frame touch 65,536 tiles each: 4.33e9
+    (triangle, tile) pairs.  The total must not wrap into something that fits."""
+    from tests.util import soup_scene
+    n = 66000
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[:, 0, :2] = (-3.0, -1.0)
+    tris[:, 1, :2] = (1.0, -1.0)
+    tris[:, 2, :2] = (1.0, 3.0)
+    tris[..., 2] = np.linspace(0.1, 0.9, n, dtype=np.float32)[:, None]
+    s = soup_scene(tris, width=8192, height=8192)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    with api.HipDrawer(8192, 8192, n_images=1) as d:
+        d.update_scene(s)
+        d.update_camera_matrices(ident, ident)
+        d.draw(0)
+        with pytest.raises(api.SxeError) as e:
+            d.sync()
+        assert e.value.code == api.E_CAPACITY and "2^32" in str(e.value)
+        # the context survives: a scene that fits renders
+        few = soup_scene(tris[:8], width=8192, height=8192)
+        d.update_scene(few)
+        d.draw(0)
+        d.sync()
+        assert (d.read_depth(0) < 1.0).all()
