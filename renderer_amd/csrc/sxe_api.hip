@@ -86,7 +86,7 @@ struct WorkBufs {
     float *pvm = nullptr;
     uint8_t *visible = nullptr;
     uint32_t *blk_count = nullptr, *tile_counters = nullptr, *bins = nullptr, *bin_keys = nullptr, *bin_pos = nullptr,
-             *walk_list = nullptr;
+             *walk_list = nullptr, *fan_order = nullptr;
     uint4 *bin_pos4 = nullptr, *tile_launch = nullptr, *bin_start = nullptr;
     RastRec *rast = nullptr;
     WideRec *wide = nullptr;
@@ -154,7 +154,7 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos, walk_list;
+    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos, walk_list, fan_order;
     DevBuf<uint4> bin_pos4, tile_launch, bin_start;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
@@ -275,6 +275,7 @@ hipError_t reserve_records(sxe_ctx *c)
     if ((e = c->bin_pos.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if ((e = c->bin_pos4.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if (c->cfg.shading != SXE_SHADE_TEXTURE && (e = c->color.reserve(n)) != hipSuccess) return e;
+    if ((e = c->fan_order.reserve(std::max<size_t>(c->fan_capacity, 1))) != hipSuccess) return e;
     return c->clip_list.reserve(c->fan_capacity);
 }
 
@@ -461,6 +462,7 @@ WorkBufs context_bufs(sxe_ctx *c, FrameSlot &fs)
     w.bin_keys = c->bin_keys.p;
     w.bin_pos = c->bin_pos.p;
     w.walk_list = c->walk_list.p;
+    w.fan_order = c->fan_order.p;
     w.bin_pos4 = c->bin_pos4.p;
     w.tile_launch = c->tile_launch.p;
     w.bin_start = c->bin_start.p;
@@ -588,6 +590,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.fan_capacity = (uint32_t)w.fan_capacity;
     sa.clip_list = w.clip_list;
     sa.walk_list = w.walk_list;
+    sa.fan_order = w.fan_order;
     sa.bin_keys = w.bin_keys;
     sa.counters = w.counters;
     sa.clip_off = w.with_clip ? 0u : 1u; // (k_setup must know whether k_clip follows)
@@ -638,6 +641,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     ra.wide = w.wide;
     ra.shade = w.shade;
     ra.color = w.color;
+    ra.fan_order = w.fan_order;
+    ra.n_slots = c->n_blocks * kSetupThreads;
     ra.counters = w.counters;
     ra.texels = c->texels.p;
     ra.textures = c->textab.p;
@@ -728,6 +733,7 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     w.shade = reinterpret_cast<ShadeRec *>(take(sizeof(ShadeRec) * recs));
     w.color = c->cfg.shading != SXE_SHADE_TEXTURE ? reinterpret_cast<ColorRec *>(take(sizeof(ColorRec) * recs)) : nullptr;
     w.clip_list = reinterpret_cast<ClipItem *>(take(sizeof(ClipItem) * kNoAllocFan));
+    w.fan_order = reinterpret_cast<uint32_t *>(take(4 * kNoAllocFan));
     fixed_bytes = at;
     if (at + 4 * 4096 > kScratchBytes) return false;
     w.bins = reinterpret_cast<uint32_t *>(base + at);
@@ -960,7 +966,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->walk_list.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->walk_list.release(); c->fan_order.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) {

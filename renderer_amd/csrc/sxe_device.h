@@ -45,11 +45,13 @@ __device__ inline Tri unpack_tri(const RastRec &r, const WideRec *__restrict__ w
     return t;
 }
 
-// 1 / doubled area, as the setup stage defines it: the reciprocal of the area converted to float.
-__device__ inline float recip_area(const Tri &t)
+// 1 / doubled area: the reciprocal of the (positive) area converted to float.  Computed once per
+// triangle by the setup stage and carried in its records.
+__device__ inline float recip_area(long long area2)
 {
-    const long long area2 = (long long)(t.x1 - t.x0) * (long long)(t.y2 - t.y0) - (long long)(t.x2 - t.x0) * (long long)(t.y1 - t.y0);
-    return 1.0f / (float)area2;
+    // (an area that fits 32 bits converts to the same float either way, in one instruction)
+    const float fa = area2 == (long long)(int32_t)area2 ? (float)(int32_t)area2 : (float)area2;
+    return 1.0f / fa;
 }
 
 // Inclusive pixel box of a triangle inside the rectangle [cx0,cx1] x [cy0,cy1].

@@ -221,6 +221,7 @@ struct ScreenTri {
     int32_t px0, px1, py0, py1; // inclusive pixel box, clamped to the frame and the scissor rows
     float zn0, zn1, zn2;        // z/w per corner (after reorientation)
     float rw0, rw1, rw2;        // 1/w per corner
+    float rA;                   // 1 / float(doubled area of t)
     bool swapped;               // corners 1 and 2 were exchanged
 };
 
@@ -287,6 +288,7 @@ __device__ inline bool setup_screen_tri(const PVert &v0, const PVert &v1, const 
     }
     if (!pixel_box(t, 0, (int32_t)g.width - 1, (int32_t)g.sy0, (int32_t)g.sy1 - 1, s.px0, s.px1, s.py0, s.py1)) return false;
     s.t = t;
+    s.rA = recip_area(area2 < 0 ? -area2 : area2);
     s.zn0 = v0.zn; s.zn1 = zn1; s.zn2 = zn2;
     s.rw0 = rw0; s.rw1 = r1; s.rw2 = r2;
     return true;
@@ -301,12 +303,12 @@ struct Attr3 {
 // colours, all in the original corner order; corners 1 and 2 are exchanged when the triangle was
 // reoriented.  The two records every triangle has are returned for the caller to store; the
 // optional ones (corners that do not fit the packed form, colour planes) are stored here.
-__device__ inline void make_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
+__device__ inline void make_records(const SetupArgs &a, uint32_t rec, const ScreenTri &s, uint32_t prim,
                                     int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb, RastRec &r, ShadeRec &h)
 {
     r.x0 = s.t.x0; r.y0 = s.t.y0;
     const int32_t dx1 = s.t.x1 - s.t.x0, dy1 = s.t.y1 - s.t.y0, dx2 = s.t.x2 - s.t.x0, dy2 = s.t.y2 - s.t.y0;
-    const bool packed = fits16(dx1) && fits16(dy1) && fits16(dx2) && fits16(dy2);
+    const bool packed = narrow(s.t); // (then every offset is below 2^14 in magnitude)
     const uint32_t d1 = ((uint32_t)dx1 & 0xFFFFu) | ((uint32_t)dy1 << 16), d2 = ((uint32_t)dx2 & 0xFFFFu) | ((uint32_t)dy2 << 16);
     r.d1 = packed ? d1 : kWideTri;
     r.d2 = packed ? d2 : 0u;
@@ -316,7 +318,7 @@ __device__ inline void make_records(const SetupArgs &a, uint32_t rec, uint32_t o
         a.wide[rec] = w;
     }
     r.z0 = s.zn0; r.dz1 = s.zn1 - s.zn0; r.dz2 = s.zn2 - s.zn0;
-    r.order = order;
+    r.rA = s.rA;
     if (s.swapped) {
         float t;
         t = u.a1; u.a1 = u.a2; u.a2 = t;
@@ -335,7 +337,7 @@ __device__ inline void make_records(const SetupArgs &a, uint32_t rec, uint32_t o
         h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
     }
     h.prim = prim;
-    h.fan_base = 0;
+    h.fan_or_ra = __float_as_uint(s.rA);
     h.tex_fan = (uint32_t)texture & 0xFFFFFFu;
     if (a.shading != SXE_SHADE_TEXTURE) {
         const float r0 = cr.a0 * s.rw0, r1 = cr.a1 * s.rw1, r2 = cr.a2 * s.rw2;
@@ -350,12 +352,12 @@ __device__ inline void make_records(const SetupArgs &a, uint32_t rec, uint32_t o
     }
 }
 
-__device__ inline void write_records(const SetupArgs &a, uint32_t rec, uint32_t order, const ScreenTri &s, uint32_t prim,
+__device__ inline void write_records(const SetupArgs &a, uint32_t rec, const ScreenTri &s, uint32_t prim,
                                      int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
 {
     RastRec r;
     ShadeRec h;
-    make_records(a, rec, order, s, prim, texture, u, v, cr, cg, cb, r, h);
+    make_records(a, rec, s, prim, texture, u, v, cr, cg, cb, r, h);
     a.rast[rec] = r;
     a.shade[rec] = h;
 }
@@ -548,9 +550,9 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // workgroup stores them as whole cache lines.
     RastRec r;
     ShadeRec h;
-    r.x0 = kNoRaster; r.y0 = 0; r.d1 = 0; r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = slot;
+    r.x0 = kNoRaster; r.y0 = 0; r.d1 = 0; r.d2 = 0; r.z0 = r.dz1 = r.dz2 = r.rA = 0.0f;
     h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
-    h.prim = prim; h.fan_base = 0; h.tex_fan = 0; // k_clip fills in the slot of a clipped triangle
+    h.prim = prim; h.fan_or_ra = 0; h.tex_fan = 0; // k_clip fills in the slot of a clipped triangle
     if (state == FAST) {
         Attr3 cr = {0, 0, 0}, cg = {0, 0, 0}, cb = {0, 0, 0};
         if (a.shading != SXE_SHADE_TEXTURE) {
@@ -562,7 +564,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
             cg = {w0.color[1], w1.color[1], w2.color[1]};
             cb = {w0.color[2], w1.color[2], w2.color[2]};
         }
-        make_records(a, slot, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
+        make_records(a, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
     }
     uint32_t reserved4[4]; // position of this lane's entry j in its bin part
 #pragma unroll
@@ -580,10 +582,10 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 4u + part : block_key);
         uint4 *sr = sh.stage, *ss = sh.stage + 2 * kSetupThreads; // raster records, then shading records
         sr[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
-        sr[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), r.order);
+        sr[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), __float_as_uint(r.rA));
         ss[3 * local] = make_uint4(__float_as_uint(h.iw0), __float_as_uint(h.diw1), __float_as_uint(h.diw2), __float_as_uint(h.uw0));
         ss[3 * local + 1] = make_uint4(__float_as_uint(h.duw1), __float_as_uint(h.duw2), __float_as_uint(h.vw0), __float_as_uint(h.dvw1));
-        ss[3 * local + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_base, h.tex_fan);
+        ss[3 * local + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_or_ra, h.tex_fan);
     }
     __syncthreads();
     if ((uint32_t)tid < total) {
@@ -664,7 +666,8 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
     ShadeRec h;
     h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
     h.prim = prim;
-    h.fan_base = a.n_blocks * kSetupThreads + fan0;
+    const uint32_t fan_base = a.n_blocks * kSetupThreads + fan0;
+    h.fan_or_ra = fan_base;
     h.tex_fan = ((uint32_t)inst.texture & 0xFFFFFFu) | ((room ? n_fan : 0u) << 24);
     a.shade[slot] = h;
     if (!room) {
@@ -672,10 +675,11 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         return;
     }
     RastRec none;
-    none.x0 = kNoRaster; none.y0 = 0; none.d1 = 0; none.d2 = 0; none.z0 = none.dz1 = none.dz2 = 0.0f; none.order = slot;
+    none.x0 = kNoRaster; none.y0 = 0; none.d1 = 0; none.d2 = 0; none.z0 = none.dz1 = none.dz2 = none.rA = 0.0f;
     for (uint32_t f = 0; f < n_fan; ++f) {
         const ClipVert &q0 = poly[0], &q1 = poly[f + 1], &q2 = poly[f + 2];
-        const uint32_t rec = h.fan_base + f;
+        const uint32_t rec = fan_base + f;
+        a.fan_order[fan0 + f] = slot; // the fan ranks where its primitive does
         ScreenTri s2;
         const PVert v0 = project_vertex(make_float4(q0.c[0], q0.c[1], q0.c[2], q0.c[3]), a.g);
         const PVert v1 = project_vertex(make_float4(q1.c[0], q1.c[1], q1.c[2], q1.c[3]), a.g);
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         }
         Attr3 u = {q0.c[4] * v0.rw, q1.c[4] * v1.rw, q2.c[4] * v2.rw}, v = {q0.c[5] * v0.rw, q1.c[5] * v1.rw, q2.c[5] * v2.rw};
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
-        write_records(a, rec, slot, s2, prim, inst.texture, u, v, cr, cg, cb);
+        write_records(a, rec, s2, prim, inst.texture, u, v, cr, cg, cb);
         count_box(a, s2);
         a.walk_list[atomicAdd(&a.counters->walk_count, 1u)] = rec; // (clipping is rare: one atomic per fan triangle)
     }

@@ -76,13 +76,18 @@ struct TexDev {
 
 // Everything the coverage/depth loop needs about one screen triangle (32 B, two 16-B loads).
 // Corners are 24.8 fixed point, oriented so that the doubled area is > 0.  Corners 1 and 2 are
-// stored as 16-bit offsets from corner 0 (x in the low half, y in the high half); a triangle whose
-// offsets do not fit sets d1 = kWideTri and keeps its corners in the WideRec of the same slot.
+// stored as 16-bit offsets from corner 0 (x in the low half, y in the high half) when the triangle
+// is narrow (its box spans fewer than 16384 sub-pixel units each way: every edge function value at
+// a pixel of the box then fits 32 bits and every product 24-bit factors); any other triangle sets
+// d1 = kWideTri and keeps its corners in the WideRec of the same slot.
+// The low half of a fragment's visibility key, the slot that ranks its triangle in submission
+// order, is the record's own slot number, except for the fan triangles of a clipped primitive,
+// which rank as their primitive does: fan_order[] holds that slot for them.
 struct __attribute__((aligned(16))) RastRec {
     int32_t x0, y0;   // x0 == kNoRaster: nothing to rasterise in this slot
     uint32_t d1, d2;
     float z0, dz1, dz2;
-    uint32_t order;   // low half of the visibility key: the slot that ranks this triangle in submission order
+    float rA;         // 1 / float(doubled area): one division per triangle instead of one per bin entry and pixel
 };
 constexpr uint32_t kWideTri = 0x80008000u; // both offsets -32768: never produced by a packed triangle
 
@@ -96,7 +101,8 @@ struct __attribute__((aligned(16))) ShadeRec {
     float duw1, duw2, vw0, dvw1;
     float dvw2;
     uint32_t prim;       // primitive id reported in the coverage buffer
-    uint32_t fan_base;   // for a clipped triangle's order slot: first fan record
+    uint32_t fan_or_ra;  // the order slot of a clipped triangle (fan count != 0): its first fan record;
+                         // every other record: the bits of RastRec::rA, so that shading needs no second load
     uint32_t tex_fan;    // texture index in the low 24 bits, fan triangle count in the high 8 (0: ordinary)
 };
 
@@ -194,6 +200,7 @@ struct SetupArgs {
     uint32_t clip_off;         // the clip kernel does not follow: a triangle that needs it voids the frame
     ClipItem *clip_list;
     uint32_t *bin_keys;        // per order slot: where k_bin files the triangle (kBinKey*)
+    uint32_t *fan_order;       // per fan record (slot - 256 * n_blocks): the order slot of its primitive
     uint32_t *walk_list;       // slots of the triangles over more than four tiles and of the fan triangles
     FrameCounters *counters;
 };
@@ -245,6 +252,8 @@ struct RasterArgs {
     const WideRec *wide;
     const ShadeRec *shade;
     const ColorRec *color;
+    const uint32_t *fan_order;  // per record past the first n_slots: the slot that ranks it
+    uint32_t n_slots;           // 256 * setup work items
     const FrameCounters *counters;
     FrameCounters *host_counters; // host-visible copy of the counters, written by the first workgroup (may be null)
     const uint8_t *texels;

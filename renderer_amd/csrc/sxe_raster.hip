@@ -102,10 +102,10 @@ hipError_t init_device_tables(int device)
     return hipSuccess;
 }
 
-constexpr int kWideQueue = 120;   // wide-box entries of one tile that all four waves share
-struct WideEntry {                // a queued triangle: corners, depth plane, submission order
+constexpr int kWideQueue = 112;   // wide-box entries of one tile that all four waves share
+struct WideEntry {                // a queued triangle: corners, depth plane, reciprocal area, submission order
     int32_t x0, y0, x1, y1, x2, y2;
-    float z0, dz1, dz2;
+    float z0, dz1, dz2, rA;
     uint32_t order;
     uint32_t box;                 // its pixel box inside the tile, see pack_box
 };
@@ -123,7 +123,6 @@ __device__ inline bool box_for_group(uint32_t box)
     return (box & kBoxNarrow) && (((box >> 10) & 31u) + 1u) * (((box >> 15) & 31u) + 1u) <= kGroupBox;
 }
 constexpr int kTexCache = 64;     // texture descriptors kept in LDS
-constexpr int kResolveBatch = 1;  // covered pixels a thread resolves together (loads of a batch overlap)
 constexpr int kEntriesPerLane = 2; // bin entries a lane fetches together
 
 __device__ inline uint32_t unorm8_encode(float a)
@@ -198,13 +197,13 @@ __device__ inline void depth_min(unsigned long long *vis, int pix, float z, uint
 // One lane walks the pixel box of one narrow triangle with 32-bit incremental edge functions, row
 // by row; the step to the next pixel is chosen between "one to the right" and "first of the next
 // row" by selects, so the loop body has no branch but the coverage test.
-__device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, int32_t bx0, int32_t bx1,
-                                   int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
+__device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const RastRec &r, uint32_t order, int32_t bx0,
+                                   int32_t bx1, int32_t by0, int32_t by1, int32_t tpx, int32_t tpy)
 {
     // every difference below is < 2^15 and every product < 2^29: exact in 32 bits
     const EdgeStart e = edge_start(t, bx0, by0);
     const int32_t b1 = e.b1, b2 = e.b2;
-    const float rA = 1.0f / (float)(mul_narrow(e.ex2, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, e.ey2));
+    const float rA = r.rA;
     const int32_t last = bx1 - bx0; // column index of a row's last pixel
     const int32_t ax0 = -256 * e.ey0, ax1 = -256 * e.ey1, ax2 = -256 * e.ey2; // one pixel to the right
     // from the last pixel of a row to the first of the next: one down, `last` to the left
@@ -219,7 +218,7 @@ __device__ inline void raster_lane(unsigned long long *vis, const Tri &t, const 
         if ((E0 | E1 | E2) >= 0) {
             const float l1 = (float)(E1 + b1) * rA, l2 = (float)(E2 + b2) * rA;
             const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-            depth_min(vis, pix, z, r.order);
+            depth_min(vis, pix, z, order);
         }
         const bool wrap = col == last;
         E0 += wrap ? aw0 : ax0;
@@ -245,7 +244,7 @@ struct WideSetup {
     bool misses;                          // an edge has the whole box on its outside: nothing to draw here
 };
 
-__device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
+__device__ inline WideSetup wide_setup(const Tri &t, bool is_narrow, float rA, int32_t bx0, int32_t bx1, int32_t by0, int32_t by1)
 {
     WideSetup w;
     w.ex0 = t.x2 - t.x1; w.ey0 = t.y2 - t.y1;
@@ -253,13 +252,13 @@ __device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, i
     w.ex2 = t.x1 - t.x0; w.ey2 = t.y1 - t.y0;
     w.b1 = edge_bias(w.ex1, w.ey1);
     w.b2 = edge_bias(w.ex2, w.ey2);
-    w.is_narrow = narrow(t);
+    w.is_narrow = is_narrow;
     const int32_t sx = 256 * bx0 + 128, sy = 256 * by0 + 128;
     // meaningful for narrow triangles only (every product below 2^28); others use the 64-bit loop
     w.R0 = mul_narrow(w.ex0, sy - t.y1) - mul_narrow(w.ey0, sx - t.x1) - edge_bias(w.ex0, w.ey0);
     w.R1 = mul_narrow(w.ex1, sy - t.y2) - mul_narrow(w.ey1, sx - t.x2) - w.b1;
     w.R2 = mul_narrow(w.ex2, sy - t.y0) - mul_narrow(w.ey2, sx - t.x0) - w.b2;
-    w.rA = recip_area(t);
+    w.rA = rA;
     w.qx0 = bx0; w.qy0 = by0;
     w.bw = (uint32_t)(bx1 - bx0 + 1);
     w.cnt = w.bw * (uint32_t)(by1 - by0 + 1);
@@ -282,10 +281,10 @@ __device__ inline WideSetup wide_setup(const Tri &t, int32_t bx0, int32_t bx1, i
 
 // Rasterise the triangle prepared by lane `src` with the whole wave.
 __device__ inline void raster_wide(unsigned long long *vis, int src, const WideSetup &w, const Tri &t, const RastRec &r,
-                                   uint32_t first, uint32_t stride, int32_t tpx, int32_t tpy)
+                                   uint32_t lane_order, uint32_t first, uint32_t stride, int32_t tpx, int32_t tpy)
 {
     const float z0 = SXE_RLF(r.z0), dz1 = SXE_RLF(r.dz1), dz2 = SXE_RLF(r.dz2), rA = SXE_RLF(w.rA);
-    const uint32_t order = (uint32_t)SXE_RL(r.order);
+    const uint32_t order = (uint32_t)SXE_RL(lane_order);
     const int32_t qx0 = SXE_RL(w.qx0), qy0 = SXE_RL(w.qy0);
     const uint32_t bw = (uint32_t)SXE_RL(w.bw), cnt = (uint32_t)SXE_RL(w.cnt), magic = (uint32_t)SXE_RL(w.magic);
     if (SXE_RL(w.is_narrow ? 1 : 0)) {
@@ -329,11 +328,142 @@ __device__ inline void raster_wide(unsigned long long *vis, int src, const WideS
     }
 }
 
+// What the resolve loop holds about one covered pixel while its records are on their way.
+struct PixelWork {
+    uint32_t pix, slot; // tile-local pixel index; the order slot of the winning triangle
+    float depth;
+    ShadeRec h;
+    uint4 geo;          // x0, y0 and the packed corner offsets of that triangle (first half of its RastRec)
+};
+
+__device__ inline void request_pixel(const RasterArgs &a, const unsigned long long *vis, const uint16_t *s_cov, uint32_t q,
+                                     PixelWork &w)
+{
+    w.pix = s_cov[q];
+    const unsigned long long key = vis[w.pix];
+    w.slot = (uint32_t)key;
+    w.depth = __uint_as_float((uint32_t)(key >> 32));
+    w.h = a.shade[w.slot];
+    w.geo = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)w.slot];
+}
+
+// Shading of one covered pixel, in two steps so that the loop can ask for the next pixel's records
+// between them, when this pixel's records are no longer needed and its texels are on their way.
+struct PixelMid { // what the second step needs
+    int32_t px, py;
+    float depth, l1, l2, riw, ax, ay;
+    uint32_t prim, slot;
+    uint32_t t00, t10, t01, t11;
+};
+
+// Step 1: barycentrics of the sample in the winning triangle, perspective division, texel
+// addresses; issues the texel loads.
+// MANYTEX: the texture table is longer than the kTexCache descriptors kept in LDS.
+template <bool MANYTEX>
+__device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, int32_t tpx, int32_t tpy, const TexDev *s_tex)
+{
+    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
+    PixelMid m;
+    const int32_t px = tpx + (int32_t)(w.pix & (kTile - 1)), py = tpy + (int32_t)(w.pix / kTile);
+    uint32_t slot = w.slot;
+    ShadeRec h = w.h;
+    RastRec r;
+    r.x0 = (int32_t)w.geo.x; r.y0 = (int32_t)w.geo.y; r.d1 = w.geo.z; r.d2 = w.geo.w;
+    r.z0 = r.dz1 = r.dz2 = r.rA = 0.0f; // (the depth plane is not needed any more; the area comes with h)
+    if (h.tex_fan >> 24) {
+        // a clipped triangle won: exactly one triangle of its fan covers this sample
+        const long long sx = 256 * px + 128, sy = 256 * py + 128;
+        const uint32_t fan_base = h.fan_or_ra, n_fan = h.tex_fan >> 24;
+        for (uint32_t f = 0; f < n_fan; ++f) {
+            const RastRec fr = a.rast[fan_base + f];
+            if (fr.x0 == kNoRaster) continue;
+            const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
+            const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
+                            fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
+            const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
+            const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
+            const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
+            if ((E0 | E1 | E2) >= 0) {
+                slot = fan_base + f;
+                r = fr;
+                break;
+            }
+        }
+        h = a.shade[slot];
+    }
+    const Tri t = unpack_tri(r, a.wide, slot);
+    const float rA = __uint_as_float(h.fan_or_ra); // (of the fan triangle that was found, for a clipped one)
+    float l1, l2;
+    if (r.d1 != kWideTri) { // narrow: same integers as below, from full-rate 24-bit multiplies
+        const int32_t sx = 256 * px + 128, sy = 256 * py + 128;
+        const int32_t E1 = mul_narrow(t.x0 - t.x2, sy - t.y2) - mul_narrow(t.y0 - t.y2, sx - t.x2);
+        const int32_t E2 = mul_narrow(t.x1 - t.x0, sy - t.y0) - mul_narrow(t.y1 - t.y0, sx - t.x0);
+        l1 = (float)E1 * rA;
+        l2 = (float)E2 * rA;
+    } else {
+        const long long sx = 256 * px + 128, sy = 256 * py + 128;
+        const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
+        const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
+        l1 = (float)E1 * rA;
+        l2 = (float)E2 * rA;
+    }
+    const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
+    const float riw = 1.0f / iw;
+    m.px = px; m.py = py; m.depth = w.depth; m.l1 = l1; m.l2 = l2; m.riw = riw; m.prim = h.prim; m.slot = slot;
+    m.ax = m.ay = 0.0f;
+    m.t00 = m.t10 = m.t01 = m.t11 = 0u;
+    if (a.shading != SXE_SHADE_VERTEX_COLOR) {
+        const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
+        const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
+        const uint32_t ti = h.tex_fan & 0xFFFFFFu;
+        // (never a choice between the two memories at run time: that would be a load through a
+        // generic pointer, which waits on both)
+        const TexDev td = MANYTEX ? a.textures[ti] : s_tex[ti];
+        const TexelQuad tq = texel_quad(td, u, v);
+        m.ax = tq.ax; m.ay = tq.ay;
+        m.t00 = texels[tq.i00]; m.t10 = texels[tq.i10]; m.t01 = texels[tq.i01]; m.t11 = texels[tq.i11];
+    }
+    return m;
+}
+
+// Step 2: filter, encode, store colour, depth and (COVERAGE) primitive id.
+template <bool COVERAGE>
+__device__ inline void shade_end(const RasterArgs &a, const PixelMid &m, const float *s_dec, const uint32_t *s_enc)
+{
+    float src[4];
+    if (a.shading == SXE_SHADE_VERTEX_COLOR) {
+        const ColorRec c = a.color[m.slot];
+        src[0] = ((c.rw0 + m.l1 * c.drw1) + m.l2 * c.drw2) * m.riw;
+        src[1] = ((c.gw0 + m.l1 * c.dgw1) + m.l2 * c.dgw2) * m.riw;
+        src[2] = ((c.bw0 + m.l1 * c.dbw1) + m.l2 * c.dbw2) * m.riw;
+        src[3] = 1.0f;
+    } else {
+        filter_quad(s_dec, m.t00, m.t10, m.t01, m.t11, m.ax, m.ay, src);
+        if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
+            const ColorRec c = a.color[m.slot];
+            src[0] = (((c.rw0 + m.l1 * c.drw1) + m.l2 * c.drw2) * m.riw) * src[0];
+            src[1] = (((c.gw0 + m.l1 * c.dgw1) + m.l2 * c.dgw2) * m.riw) * src[1];
+            src[2] = (((c.bw0 + m.l1 * c.dbw1) + m.l2 * c.dbw2) * m.riw) * src[2];
+        }
+    }
+    // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target:
+    // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 in every shading mode
+    // (textures must be opaque, vertex colours have no alpha), and then the blend returns Cs and 1
+    // bit for bit, so it is not evaluated.
+    const uint32_t cr = srgb_encode_lds(s_enc, src[0]);
+    const uint32_t cg = srgb_encode_lds(s_enc, src[1]);
+    const uint32_t cb = srgb_encode_lds(s_enc, src[2]);
+    const size_t p = (size_t)(__umul24((uint32_t)m.py, a.g.width) + (uint32_t)m.px); // (frames are at most 8192 wide and high)
+    reinterpret_cast<uint32_t *>(a.out_color)[p] = cr | (cg << 8) | (cb << 16) | 0xFF000000u;
+    a.out_depth[p] = m.depth;
+    if (COVERAGE) a.out_prim[p] = m.prim;
+}
+
 // (seven resident workgroups per compute unit: 72 registers and at most 22 KB of LDS, which is
 // handed out in 1 KB pieces; eight would need spills)
 // COVERAGE: the frame keeps a primitive-id image.  DEV: built with the development switches of
 // RasterArgs::debug and the per-tile clock stamps; the ordinary build has none of their tests.
-template <bool COVERAGE, bool DEV>
+template <bool COVERAGE, bool DEV, bool MANYTEX>
 __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_raster_shade(RasterArgs a)
 {
     if (!DEV) {
@@ -409,6 +539,10 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const bool valid = slots[k] != 0xFFFFFFFFu;
             bool wide_box = false;
             const RastRec r = recs[k];
+            // what ranks the triangle among the fragments of a pixel: its slot, or for a fan
+            // triangle of a clipped primitive (rare) the slot of that primitive
+            uint32_t order = slots[k];
+            if (valid && order >= a.n_slots) order = a.fan_order[order - a.n_slots];
             Tri t = {0, 0, 0, 0, 0, 0};
             int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
             bool nonempty = false, is_narrow = false;
@@ -416,7 +550,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             if (valid) {
                 t = unpack_tri(r, a.wide, slots[k]);
                 nonempty = pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
-                is_narrow = narrow(t);
+                is_narrow = r.d1 != kWideTri;
                 box_px = mul_narrow(bx1 - bx0 + 1, by1 - by0 + 1);
             }
             // Boxes of 25 to 64 pixels: when a wave holds many of them its lanes are evenly loaded
@@ -427,7 +561,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             if (valid) {
                 const bool alone = nonempty && box_px <= lane_box && is_narrow;
                 wide_box = nonempty && !alone && !(a.debug & kDebugSkipLarge);
-                if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, bx0, bx1, by0, by1, tpx, tpy);
+                if (alone && !(a.debug & kDebugSkipSmall)) raster_lane(vis, t, r, order, bx0, bx1, by0, by1, tpx, tpy);
                 if (a.debug & kDebugSkipAtomic) { // development census of the two raster paths
                     FrameCounters *ctr = const_cast<FrameCounters *>(a.counters);
                     const uint32_t box = (uint32_t)box_px;
@@ -441,7 +575,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
                         // the whole triangle, so that the second pass needs no memory access
                         WideEntry q;
                         q.x0 = t.x0; q.y0 = t.y0; q.x1 = t.x1; q.y1 = t.y1; q.x2 = t.x2; q.y2 = t.y2;
-                        q.z0 = r.z0; q.dz1 = r.dz1; q.dz2 = r.dz2; q.order = r.order;
+                        q.z0 = r.z0; q.dz1 = r.dz1; q.dz2 = r.dz2; q.rA = r.rA; q.order = order;
                         q.box = pack_box(bx0, bx1, by0, by1, tpx, tpy, is_narrow);
                         s_wq[qi] = q;
                         wide_box = false;
@@ -451,12 +585,12 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             // queue full: this wave walks the box on its own, 64 pixels per step
             unsigned long long lm = __ballot(wide_box);
             if (lm) {
-                const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
+                const WideSetup ws = wide_setup(t, is_narrow, r.rA, bx0, bx1, by0, by1);
                 lm = __ballot(wide_box && !ws.misses);
                 while (lm) {
                     const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
                     lm &= lm - 1;
-                    raster_wide(vis, src, ws, t, r, (uint32_t)lane, 64u, tpx, tpy);
+                    raster_wide(vis, src, ws, t, r, order, (uint32_t)lane, 64u, tpx, tpy);
                 }
             }
           }
@@ -477,7 +611,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const uint32_t bw = ((q.box >> 10) & 31u) + 1u, cnt = bw * (((q.box >> 15) & 31u) + 1u);
             const Tri t = {q.x0, q.y0, q.x1, q.y1, q.x2, q.y2};
             const EdgeStart es = edge_start(t, bx0, by0);
-            const float rA = 1.0f / (float)(mul_narrow(es.ex2, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, es.ey2));
+            const float rA = q.rA;
             const int32_t ax0 = -256 * es.ey0, ax1 = -256 * es.ey1, ax2 = -256 * es.ey2; // one pixel to the right
             const int32_t ay0 = 256 * es.ex0, ay1 = 256 * es.ex1, ay2 = 256 * es.ex2;    // one pixel down
             const uint32_t magic = s_magic[bw];
@@ -500,21 +634,25 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const uint32_t e = base + (uint32_t)lane;
             const bool valid = e < nq && !box_for_group(s_wq[min(e, (uint32_t)kWideQueue - 1u)].box);
             RastRec r;
-            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = 0.0f; r.order = 0;
+            r.x0 = r.y0 = 0; r.d1 = r.d2 = 0; r.z0 = r.dz1 = r.dz2 = r.rA = 0.0f;
+            uint32_t order = 0;
+            bool is_narrow = true;
             Tri t = {0, 0, 0, 0, 0, 0};
             int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
             if (valid) {
                 const WideEntry q = s_wq[e];
                 t.x0 = q.x0; t.y0 = q.y0; t.x1 = q.x1; t.y1 = q.y1; t.x2 = q.x2; t.y2 = q.y2;
-                r.z0 = q.z0; r.dz1 = q.dz1; r.dz2 = q.dz2; r.order = q.order;
+                r.z0 = q.z0; r.dz1 = q.dz1; r.dz2 = q.dz2; r.rA = q.rA;
+                order = q.order;
+                is_narrow = (q.box & kBoxNarrow) != 0u;
                 pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1);
             }
-            const WideSetup ws = wide_setup(t, bx0, bx1, by0, by1);
+            const WideSetup ws = wide_setup(t, is_narrow, r.rA, bx0, bx1, by0, by1);
             unsigned long long lm = __ballot(valid && !ws.misses);
             while (lm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)lm) - 1);
                 lm &= lm - 1;
-                raster_wide(vis, src, ws, t, r, (uint32_t)(wave * 64 + lane), (uint32_t)kRasterThreads, tpx, tpy);
+                raster_wide(vis, src, ws, t, r, order, (uint32_t)(wave * 64 + lane), (uint32_t)kRasterThreads, tpx, tpy);
             }
         }
     }
@@ -525,10 +663,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
         return;
     }
 
-    // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target.
-    // A thread owns kTilePixels / kRasterThreads pixels and handles them kResolveBatch at a time,
-    // stage by stage, so that the dependent loads of one stage are in flight together. ----
-    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
+    // ---- resolve: shade the winning triangle of every pixel once, blend over the cleared target ----
     // Uncovered pixels only need the clear values; covered ones are gathered into a dense list
     // first so that the shading loop runs with full waves.
     for (int k = 0; k < kTilePixels / kRasterThreads; ++k) {
@@ -553,162 +688,33 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();
     SXE_STAMP(5);
     const uint32_t n_cov = s_ncov;
-    // The records of a thread's next pixel are requested before its current pixel is shaded, so
-    // that their round trip overlaps the texel fetches of the current one.
-    ShadeRec h_next;
-    uint4 geo_next = make_uint4(0, 0, 0, 0); // x0, y0 and the packed corner offsets of the winning triangle
-    uint32_t slot_next = 0, pix_next = 0;
-    float depth_next = 1.0f;
-    h_next.iw0 = h_next.diw1 = h_next.diw2 = h_next.uw0 = h_next.duw1 = h_next.duw2 = h_next.vw0 = h_next.dvw1 = h_next.dvw2 = 0.0f;
-    h_next.prim = h_next.fan_base = h_next.tex_fan = 0;
-#define SXE_REQUEST(q)                                                                     \
-    do {                                                                                   \
-        pix_next = s_cov[(q)];                                                             \
-        const unsigned long long key_ = vis[pix_next];                                     \
-        slot_next = (uint32_t)key_;                                                        \
-        depth_next = __uint_as_float((uint32_t)(key_ >> 32));                              \
-        h_next = a.shade[slot_next];                                                       \
-        geo_next = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)slot_next];         \
-    } while (0)
-    if ((uint32_t)tid < n_cov) SXE_REQUEST(tid);
-    for (uint32_t q0 = (uint32_t)tid; q0 < n_cov; q0 += kRasterThreads * kResolveBatch) {
-        bool live[kResolveBatch], cov[kResolveBatch];
-        uint32_t slot[kResolveBatch], prim[kResolveBatch], code[kResolveBatch];
-        float depth[kResolveBatch];
-        int32_t px[kResolveBatch], py[kResolveBatch];
-        ShadeRec h[kResolveBatch];
-        RastRec r[kResolveBatch];
-        static_assert(kResolveBatch == 1, "the request-ahead scheme handles one pixel per thread and round");
-        live[0] = cov[0] = true;
-        px[0] = tpx + (int32_t)(pix_next & (kTile - 1));
-        py[0] = tpy + (int32_t)(pix_next / kTile);
-        slot[0] = slot_next;
-        depth[0] = depth_next;
-        prim[0] = 0xFFFFFFFFu;
-        code[0] = a.clear_code;
-        h[0] = h_next;
-        r[0].x0 = (int32_t)geo_next.x; r[0].y0 = (int32_t)geo_next.y; r[0].d1 = geo_next.z; r[0].d2 = geo_next.w;
-        r[0].z0 = r[0].dz1 = r[0].dz2 = 0.0f; r[0].order = slot_next; // the depth planes are not needed any more
-        if (q0 + kRasterThreads < n_cov) SXE_REQUEST(q0 + kRasterThreads);
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b)
-            if (cov[b] && (h[b].tex_fan >> 24)) {
-                // a clipped triangle won: exactly one triangle of its fan covers this sample
-                const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
-                const uint32_t fan_base = h[b].fan_base, n_fan = h[b].tex_fan >> 24;
-                for (uint32_t f = 0; f < n_fan; ++f) {
-                    const RastRec fr = a.rast[fan_base + f];
-                    if (fr.x0 == kNoRaster) continue;
-                    const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
-                    const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
-                                    fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
-                    const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
-                    const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
-                    const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
-                    if ((E0 | E1 | E2) >= 0) {
-                        slot[b] = fan_base + f;
-                        r[b] = fr;
-                        break;
-                    }
-                }
-                h[b] = a.shade[slot[b]];
-            }
-        float l1[kResolveBatch], l2[kResolveBatch], riw[kResolveBatch];
-        TexelQuad tq[kResolveBatch];
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b)
-            if (cov[b]) {
-                const Tri t = unpack_tri(r[b], a.wide, slot[b]);
-                prim[b] = h[b].prim;
-                if (narrow(t)) { // same integers as below, from full-rate 24-bit multiplies
-                    const int32_t sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
-                    const int32_t area2 = mul_narrow(t.x1 - t.x0, t.y2 - t.y0) - mul_narrow(t.x2 - t.x0, t.y1 - t.y0);
-                    const int32_t E1 = mul_narrow(t.x0 - t.x2, sy - t.y2) - mul_narrow(t.y0 - t.y2, sx - t.x2);
-                    const int32_t E2 = mul_narrow(t.x1 - t.x0, sy - t.y0) - mul_narrow(t.y1 - t.y0, sx - t.x0);
-                    const float rA = 1.0f / (float)area2;
-                    l1[b] = (float)E1 * rA;
-                    l2[b] = (float)E2 * rA;
-                } else {
-                    const float rA = recip_area(t);
-                    const long long sx = 256 * px[b] + 128, sy = 256 * py[b] + 128;
-                    const long long E1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);
-                    const long long E2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);
-                    l1[b] = (float)E1 * rA;
-                    l2[b] = (float)E2 * rA;
-                }
-                const float iw = (h[b].iw0 + l1[b] * h[b].diw1) + l2[b] * h[b].diw2;
-                riw[b] = 1.0f / iw;
-                if (a.shading != SXE_SHADE_VERTEX_COLOR) {
-                    const float u = ((h[b].uw0 + l1[b] * h[b].duw1) + l2[b] * h[b].duw2) * riw[b];
-                    const float v = ((h[b].vw0 + l1[b] * h[b].dvw1) + l2[b] * h[b].dvw2) * riw[b];
-                    const uint32_t ti = h[b].tex_fan & 0xFFFFFFu;
-                    const TexDev td = ti < (uint32_t)kTexCache ? s_tex[ti] : a.textures[ti];
-                    tq[b] = texel_quad(td, u, v);
-                }
-            }
-        uint32_t t00[kResolveBatch], t10[kResolveBatch], t01[kResolveBatch], t11[kResolveBatch];
-        if (a.shading != SXE_SHADE_VERTEX_COLOR) {
-#pragma unroll
-            for (int b = 0; b < kResolveBatch; ++b)
-                if (cov[b]) {
-                    t00[b] = texels[tq[b].i00]; t10[b] = texels[tq[b].i10];
-                    t01[b] = texels[tq[b].i01]; t11[b] = texels[tq[b].i11];
-                }
-        }
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b)
-            if (cov[b]) {
-                float src[4];
-                if (a.shading == SXE_SHADE_VERTEX_COLOR) {
-                    const ColorRec c = a.color[slot[b]];
-                    src[0] = ((c.rw0 + l1[b] * c.drw1) + l2[b] * c.drw2) * riw[b];
-                    src[1] = ((c.gw0 + l1[b] * c.dgw1) + l2[b] * c.dgw2) * riw[b];
-                    src[2] = ((c.bw0 + l1[b] * c.dbw1) + l2[b] * c.dbw2) * riw[b];
-                    src[3] = 1.0f;
-                } else {
-                    filter_quad(s_dec, t00[b], t10[b], t01[b], t11[b], tq[b].ax, tq[b].ay, src);
-                    if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
-                        const ColorRec c = a.color[slot[b]];
-                        src[0] = (((c.rw0 + l1[b] * c.drw1) + l2[b] * c.drw2) * riw[b]) * src[0];
-                        src[1] = (((c.gw0 + l1[b] * c.dgw1) + l2[b] * c.dgw2) * riw[b]) * src[1];
-                        src[2] = (((c.bw0 + l1[b] * c.dbw1) + l2[b] * c.dbw2) * riw[b]) * src[2];
-                    }
-                }
-                // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target:
-                // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 in every
-                // shading mode (textures must be opaque, vertex colours have no alpha), and then
-                // the blend returns Cs and 1 bit for bit, so it is not evaluated.
-                const uint32_t cr = srgb_encode_lds(s_enc, src[0]);
-                const uint32_t cg = srgb_encode_lds(s_enc, src[1]);
-                const uint32_t cb = srgb_encode_lds(s_enc, src[2]);
-                code[b] = cr | (cg << 8) | (cb << 16) | 0xFF000000u;
-            }
-#pragma unroll
-        for (int b = 0; b < kResolveBatch; ++b)
-            if (live[b]) {
-                const size_t p = (size_t)(__umul24((uint32_t)py[b], a.g.width) + (uint32_t)px[b]);
-                reinterpret_cast<uint32_t *>(a.out_color)[p] = code[b];
-                a.out_depth[p] = depth[b];
-                if (COVERAGE) a.out_prim[p] = prim[b];
-            }
+    // The records of a thread's next pixel are requested while the texels of the current one are
+    // on their way: their round trip overlaps the filtering, encoding and storing of this pixel.
+    PixelWork w, w_next;
+    if ((uint32_t)tid < n_cov) request_pixel(a, vis, s_cov, (uint32_t)tid, w_next);
+    for (uint32_t q = (uint32_t)tid; q < n_cov; q += kRasterThreads) {
+        w = w_next;
+        if (q + kRasterThreads < n_cov) request_pixel(a, vis, s_cov, q + kRasterThreads, w_next);
+        const PixelMid m = shade_begin<MANYTEX>(a, w, tpx, tpy, s_tex);
+        shade_end<COVERAGE>(a, m, s_dec, s_enc);
     }
-#undef SXE_REQUEST
     SXE_STAMP(7);
 }
 
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 {
     if (a.g.n_tiles == 0) return hipSuccess;
-    const bool dev = a.debug != 0u || a.tile_times != nullptr;
+    const bool dev = a.debug != 0u || a.tile_times != nullptr, many = a.n_textures > (uint32_t)kTexCache;
     const dim3 grid(a.g.n_tiles), block(kRasterThreads);
-    if (a.out_prim && dev)
-        hipLaunchKernelGGL((k_raster_shade<true, true>), grid, block, 0, s, a);
-    else if (a.out_prim)
-        hipLaunchKernelGGL((k_raster_shade<true, false>), grid, block, 0, s, a);
-    else if (dev)
-        hipLaunchKernelGGL((k_raster_shade<false, true>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((k_raster_shade<false, false>), grid, block, 0, s, a);
+#define SXE_LAUNCH(C, D, M) hipLaunchKernelGGL((k_raster_shade<C, D, M>), grid, block, 0, s, a)
+    if (a.out_prim) {
+        if (dev) { if (many) SXE_LAUNCH(true, true, true); else SXE_LAUNCH(true, true, false); }
+        else     { if (many) SXE_LAUNCH(true, false, true); else SXE_LAUNCH(true, false, false); }
+    } else {
+        if (dev) { if (many) SXE_LAUNCH(false, true, true); else SXE_LAUNCH(false, true, false); }
+        else     { if (many) SXE_LAUNCH(false, false, true); else SXE_LAUNCH(false, false, false); }
+    }
+#undef SXE_LAUNCH
     return hipGetLastError();
 }
 
