@@ -99,8 +99,7 @@ pub struct sxe_timings {
     pub transform_ms: f32,
     pub object_ms: f32,
     pub setup_ms: f32,
-    pub scan_ms: f32,
-    pub bin_ms: f32,
+    pub finish_ms: f32,
     pub raster_shade_ms: f32,
     pub frame_ms: f32,
 }

@@ -111,7 +111,7 @@ typedef struct {
  * A rotation-system update is applied by the frame's first kernel and counted in object_ms;
  * transform_ms is 0. */
 typedef struct {
-    float transform_ms, object_ms, setup_ms, scan_ms, bin_ms, raster_shade_ms, frame_ms;
+    float transform_ms, object_ms, setup_ms, finish_ms, raster_shade_ms, frame_ms;
 } sxe_timings;
 
 /* Work counters of the last synchronised frame. */
@@ -174,10 +174,11 @@ int sxe_sync(sxe_ctx *ctx);
  * work buffer of the frame (per-object matrices, triangle records, bin tables, bins) lives in a
  * static device array of SXE_NOALLOC_SCRATCH_BYTES that is part of the library's code object; the
  * call makes no hipMalloc/hipFree and returns when the frame is finished.  Scenes whose work buffers
- * do not fit fail with SXE_E_CAPACITY instead of growing anything: the array must hold about 124 bytes
- * per submitted triangle (172 with a vertex-colour shading mode; objects count in steps of 256
- * triangles), 72 bytes per screen tile and 4 bytes per (triangle, tile) bin entry, which is room for
- * roughly 200,000 triangles.  No frame of sxe_draw may
+ * do not fit fail with SXE_E_CAPACITY instead of growing anything: the array must hold about 100 bytes
+ * per submitted triangle (148 with a vertex-colour shading mode; objects count in steps of 256
+ * triangles) and 72 bytes per screen tile; what is left is divided evenly among the tiles for their
+ * bins (4 bytes per entry), and a frame whose fullest tile needs more than its share fails as well.
+ * Room for roughly 200,000 triangles at 1080p.  No frame of sxe_draw may
  * be in flight on the context (SXE_E_STATE; call sxe_sync first).  Every call on one GPU uses that
  * GPU's one array, from whatever context or thread: calls that overlap on a GPU race. */
 int sxe_draw_noalloc(sxe_ctx *ctx, uint32_t image_index);

@@ -75,8 +75,8 @@ assert INSTANCE.itemsize == C.sizeof(InstanceC) == 52
 
 
 class Timings(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("transform_ms", "object_ms", "setup_ms", "scan_ms",
-                                         "bin_ms", "raster_shade_ms", "frame_ms")]
+    _fields_ = [(n, C.c_float) for n in ("transform_ms", "object_ms", "setup_ms", "finish_ms",
+                                         "raster_shade_ms", "frame_ms")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}

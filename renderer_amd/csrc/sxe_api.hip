@@ -58,7 +58,7 @@ struct Image {
     bool drawn = false;
 };
 
-enum { EV_BEGIN = 0, EV_OBJECT, EV_SETUP, EV_SCAN, EV_BIN, EV_RASTER, EV_N };
+enum { EV_BEGIN = 0, EV_OBJECT, EV_SETUP, EV_FINISH, EV_RASTER, EV_N };
 
 // Frames are enqueued without waiting for the one before (the reference keeps one frame per
 // swapchain image in flight the same way, src/renderer/drawer.rs:416-424).  What has to outlive a
@@ -85,16 +85,16 @@ struct FrameSlot {
 struct WorkBufs {
     float *pvm = nullptr;
     uint8_t *visible = nullptr;
-    uint32_t *blk_count = nullptr, *tile_counters = nullptr, *bins = nullptr, *bin_keys = nullptr, *bin_pos = nullptr,
-             *walk_list = nullptr, *fan_order = nullptr;
-    uint4 *bin_pos4 = nullptr, *tile_launch = nullptr, *bin_start = nullptr;
+    uint32_t *blk_count = nullptr, *tile_counters = nullptr, *bins = nullptr, *walk_list = nullptr, *fan_order = nullptr;
+    TileLaunch *tile_launch = nullptr;
+    BinLayout bl = {};
     RastRec *rast = nullptr;
     WideRec *wide = nullptr;
     ClipItem *clip_list = nullptr;
     ShadeRec *shade = nullptr;
     ColorRec *color = nullptr;
     FrameCounters *counters = nullptr;
-    size_t fan_capacity = 0, bin_capacity = 0;
+    size_t fan_capacity = 0;
     bool with_clip = true; // k_clip follows k_setup
 };
 
@@ -154,8 +154,8 @@ struct sxe_ctx {
     Mat4 view, proj, pv;
 
     // per-frame work buffers
-    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, bin_keys, bin_pos, walk_list, fan_order;
-    DevBuf<uint4> bin_pos4, tile_launch, bin_start;
+    DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, walk_list, fan_order;
+    DevBuf<TileLaunch> tile_launch;
     DevBuf<RastRec> rast;
     DevBuf<WideRec> wide;
     DevBuf<ClipItem> clip_list;
@@ -164,7 +164,8 @@ struct sxe_ctx {
     DevBuf<FrameCounters> counters;
     DevBuf<float4> clip;
     DevBuf<unsigned long long> tile_times;
-    size_t fan_capacity = 0, bin_capacity = 0; // records past the per-workgroup segments; bin entries
+    size_t fan_capacity = 0; // records past the per-workgroup segments
+    BinLayout bl = {};       // capacities of the five bin regions every tile has; the bin array holds n_tiles * bl.stride entries
 
     std::vector<Image> images;
     FrameSlot slots[kFrameSlots];
@@ -271,12 +272,39 @@ hipError_t reserve_records(sxe_ctx *c)
     if ((e = c->wide.reserve(n)) != hipSuccess) return e;
     if ((e = c->shade.reserve(n)) != hipSuccess) return e;
     if ((e = c->walk_list.reserve(n)) != hipSuccess) return e;
-    if ((e = c->bin_keys.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
-    if ((e = c->bin_pos.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
-    if ((e = c->bin_pos4.reserve(std::max<size_t>((size_t)c->n_blocks * kSetupThreads, 1))) != hipSuccess) return e;
     if (c->cfg.shading != SXE_SHADE_TEXTURE && (e = c->color.reserve(n)) != hipSuccess) return e;
     if ((e = c->fan_order.reserve(std::max<size_t>(c->fan_capacity, 1))) != hipSuccess) return e;
     return c->clip_list.reserve(c->fan_capacity);
+}
+
+// Region capacities are rounded up to 64 entries, so that a region starts on a 256-byte boundary.
+void layout_from_caps(BinLayout &bl, const uint32_t cap[kBinRegions])
+{
+    uint32_t at = 0;
+    for (int r = 0; r < kBinRegions; ++r) {
+        bl.cap[r] = (cap[r] + 63u) & ~63u;
+        bl.off[r] = at;
+        at += bl.cap[r];
+    }
+    bl.stride = at;
+}
+
+// Makes every region at least `want` entries large (never smaller than it is) and sizes the bin array.
+int set_bin_layout(sxe_ctx *c, const uint32_t want[kBinRegions])
+{
+    uint32_t cap[kBinRegions];
+    uint64_t stride = 0;
+    for (int r = 0; r < kBinRegions; ++r) {
+        cap[r] = std::max(want[r], c->bl.cap[r]);
+        stride += ((uint64_t)cap[r] + 63u) & ~(uint64_t)63u;
+    }
+    const uint64_t total = stride * std::max<uint32_t>(c->g.n_tiles, 1);
+    if (total > 0xFFFFFFF0ull)
+        return fail(c, SXE_E_CAPACITY, "bins of %llu entries per tile for %u tiles exceed 2^32 entries", (unsigned long long)stride,
+                    c->g.n_tiles);
+    layout_from_caps(c->bl, cap);
+    SXE_HIP(c, c->bins.reserve((size_t)total));
+    return SXE_OK;
 }
 
 // Shared tail of update_drawables / update_instances: pools the meshes, derives the draw list
@@ -442,10 +470,14 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     // every setup work item owns 256 record slots; fans of clipped triangles follow them
     if (c->fan_capacity < 4096) c->fan_capacity = 4096;
     SXE_HIP(c, reserve_records(c));
-    const size_t want_bin = std::max<size_t>(4096, (size_t)(prims / 2 + 4 * (uint64_t)c->g.n_tiles));
-    if (want_bin > c->bin_capacity) {
-        SXE_HIP(c, c->bins.reserve(want_bin));
-        c->bin_capacity = want_bin;
+    // bins: room for four times the mean number of entries a tile would get if half of the
+    // triangles survived, split 4 : 4 : 2 : 1 over the size classes
+    {
+        const uint64_t mean = prims / 2 / std::max<uint32_t>(c->g.n_tiles, 1);
+        const uint32_t base = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(64, 4 * mean));
+        const uint32_t want[kBinRegions] = {base, base, base / 2, base / 4, 64};
+        const int rc = set_bin_layout(c, want);
+        if (rc) return rc;
     }
     return SXE_OK;
 }
@@ -459,13 +491,9 @@ WorkBufs context_bufs(sxe_ctx *c, FrameSlot &fs)
     w.blk_count = c->blk_count.p;
     w.tile_counters = c->tile_counters.p;
     w.bins = c->bins.p;
-    w.bin_keys = c->bin_keys.p;
-    w.bin_pos = c->bin_pos.p;
     w.walk_list = c->walk_list.p;
     w.fan_order = c->fan_order.p;
-    w.bin_pos4 = c->bin_pos4.p;
     w.tile_launch = c->tile_launch.p;
-    w.bin_start = c->bin_start.p;
     w.rast = c->rast.p;
     w.wide = c->wide.p;
     w.clip_list = c->clip_list.p;
@@ -473,7 +501,7 @@ WorkBufs context_bufs(sxe_ctx *c, FrameSlot &fs)
     w.color = c->color.p;
     w.counters = c->counters.p;
     w.fan_capacity = c->fan_capacity;
-    w.bin_capacity = c->bin_capacity;
+    w.bl = c->bl;
     w.with_clip = c->clip_enabled;
     return w;
 }
@@ -581,8 +609,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.g = c->g;
     sa.blk_count = w.blk_count;
     sa.tiles = reinterpret_cast<TileCtr *>(w.tile_counters);
-    sa.bin_pos = w.bin_pos;
-    sa.bin_pos4 = w.bin_pos4;
+    sa.bins = w.bins;
+    sa.bl = w.bl;
     sa.rast = w.rast;
     sa.wide = w.wide;
     sa.shade = w.shade;
@@ -591,52 +619,34 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.clip_list = w.clip_list;
     sa.walk_list = w.walk_list;
     sa.fan_order = w.fan_order;
-    sa.bin_keys = w.bin_keys;
     sa.counters = w.counters;
     sa.clip_off = w.with_clip ? 0u : 1u; // (k_setup must know whether k_clip follows)
     SXE_HIP(c, launch_setup(sa, s));
     if (w.with_clip) SXE_HIP(c, launch_clip(sa, s));
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SETUP], s));
 
-    ScanArgs sc{};
-    sc.blk_count = w.blk_count;
-    sc.n_blocks = c->n_blocks;
-    sc.tiles = sa.tiles;
-    sc.bin_start = w.bin_start;
-    sc.tile_order = w.tile_counters + 9 * ntc;
-    sc.n_tiles = nt;
-    sc.bin_capacity = (uint32_t)std::min<size_t>(w.bin_capacity, 0xFFFFFFFFu);
-    sc.counters = w.counters;
-    SXE_HIP(c, launch_scan(sc, s));
-    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SCAN], s));
-
-    BinArgs ba{};
-    ba.g = c->g;
-    ba.blk_count = w.blk_count;
-    ba.n_blocks = c->n_blocks;
-    ba.walk_blocks = 256; // 1024 waves share the list of late entries, however long it is
-    ba.rast = w.rast;
-    ba.wide = w.wide;
-    ba.bin_keys = w.bin_keys;
-    ba.bin_pos = w.bin_pos;
-    ba.bin_pos4 = w.bin_pos4;
-    ba.tiles = sa.tiles;
-    ba.bin_start = reinterpret_cast<const uint32_t *>(w.bin_start);
-    ba.late_fill = w.tile_counters + 8 * ntc;
-    ba.tile_order = sc.tile_order;
-    ba.tile_launch = w.tile_launch;
-    ba.bins = w.bins;
-    ba.counters = w.counters;
-    ba.walk_list = w.walk_list;
-    // the binning switches leave the bins unusable: only honoured when the tile kernel skips them
-    ba.debug = (c->cfg.flags & kDebugSkipRaster) ? (c->cfg.flags & kDebugMask) : 0u;
-    SXE_HIP(c, launch_bin(ba, s));
-    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BIN], s));
+    FinishArgs fa{};
+    fa.g = c->g;
+    fa.blk_count = w.blk_count;
+    fa.n_blocks = c->n_blocks;
+    fa.walk_blocks = 128; // 1024 waves share the list of late entries, however long it is
+    fa.rast = w.rast;
+    fa.wide = w.wide;
+    fa.walk_list = w.walk_list;
+    fa.tiles = sa.tiles;
+    fa.late_fill = w.tile_counters + 8 * ntc;
+    fa.tile_launch = w.tile_launch;
+    fa.bins = w.bins;
+    fa.bl = w.bl;
+    fa.counters = w.counters;
+    SXE_HIP(c, launch_finish(fa, s));
+    if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_FINISH], s));
 
     RasterArgs ra{};
     ra.g = c->g;
     ra.tile_launch = w.tile_launch;
     ra.bins = w.bins;
+    ra.bl = w.bl;
     ra.rast = w.rast;
     ra.wide = w.wide;
     ra.shade = w.shade;
@@ -680,15 +690,17 @@ int grow_for(sxe_ctx *c, const FrameSlot &fs)
     // a full clip list hides how many fans its overflow would have produced: at most 7 each
     const size_t fans = std::max<size_t>(k.fan_records, k.clip_count > c->fan_capacity ? (size_t)k.clip_count * kMaxFan : 0);
     const size_t need_fan = fans + fans / 4 + 1024;
-    const size_t need_bin = (size_t)k.total_pairs + (size_t)k.total_pairs / 4 + 1024;
     if (need_fan > c->fan_capacity) {
         c->fan_capacity = need_fan;
         SXE_HIP(c, reserve_records(c));
     }
-    if (need_bin > c->bin_capacity) {
-        SXE_HIP(c, c->bins.reserve(need_bin));
-        c->bin_capacity = need_bin;
+    uint32_t want[kBinRegions];
+    bool grow = false;
+    for (int r = 0; r < kBinRegions; ++r) {
+        want[r] = k.need[r] > c->bl.cap[r] ? k.need[r] + k.need[r] / 4 + 16 : c->bl.cap[r];
+        grow = grow || k.need[r] > c->bl.cap[r];
     }
+    if (grow) return set_bin_layout(c, want);
     return SXE_OK;
 }
 
@@ -720,13 +732,9 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     w.counters = reinterpret_cast<FrameCounters *>(take(sizeof(FrameCounters)));
     w.blk_count = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(c->n_blocks, 1)));
     w.tile_counters = reinterpret_cast<uint32_t *>(take(4 * 10 * ntc));
-    w.tile_launch = reinterpret_cast<uint4 *>(take(16 * ntc));
-    w.bin_start = reinterpret_cast<uint4 *>(take(16 * ntc));
+    w.tile_launch = reinterpret_cast<TileLaunch *>(take(sizeof(TileLaunch) * ntc));
     w.pvm = reinterpret_cast<float *>(take(64 * nobj));
     w.visible = reinterpret_cast<uint8_t *>(take(nobj));
-    w.bin_keys = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(slots, 1)));
-    w.bin_pos = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(slots, 1)));
-    w.bin_pos4 = reinterpret_cast<uint4 *>(take(16 * std::max<size_t>(slots, 1)));
     w.walk_list = reinterpret_cast<uint32_t *>(take(4 * recs));
     w.rast = reinterpret_cast<RastRec *>(take(sizeof(RastRec) * recs));
     w.wide = reinterpret_cast<WideRec *>(take(sizeof(WideRec) * recs));
@@ -735,9 +743,14 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     w.clip_list = reinterpret_cast<ClipItem *>(take(sizeof(ClipItem) * kNoAllocFan));
     w.fan_order = reinterpret_cast<uint32_t *>(take(4 * kNoAllocFan));
     fixed_bytes = at;
-    if (at + 4 * 4096 > kScratchBytes) return false;
+    // the bins get the rest: the same number of entries for every tile, split 4 : 4 : 2 : 1 : 1 over
+    // the size classes and the late entries
+    const size_t per_tile = at < kScratchBytes ? (kScratchBytes - at) / 4 / ntc : 0;
+    if (per_tile < 12 * 64) return false;
+    const uint32_t unit = (uint32_t)std::min<size_t>(per_tile / 12 / 64 * 64, 1u << 20);
+    const uint32_t cap[kBinRegions] = {4 * unit, 4 * unit, 2 * unit, unit, unit};
+    layout_from_caps(w.bl, cap);
     w.bins = reinterpret_cast<uint32_t *>(base + at);
-    w.bin_capacity = (kScratchBytes - at) / 4;
     w.fan_capacity = kNoAllocFan;
     w.with_clip = true; // always: a frame that finds a triangle to clip cannot be drawn again here
     return true;
@@ -798,16 +811,15 @@ int retire_oldest(sxe_ctx *c)
         sxe_timings &t = c->timings;
         t.object_ms = ms[EV_OBJECT];
         t.setup_ms = ms[EV_SETUP];
-        t.scan_ms = ms[EV_SCAN];
-        t.bin_ms = ms[EV_BIN];
+        t.finish_ms = ms[EV_FINISH];
         t.raster_shade_ms = ms[EV_RASTER];
         SXE_HIP(c, hipEventElapsedTime(&t.frame_ms, fs.ev[EV_BEGIN], fs.ev[EV_RASTER]));
         t.transform_ms = 0.0f;
         if (fs.transform_timed) SXE_HIP(c, hipEventElapsedTime(&t.transform_ms, fs.ev_tr[0], fs.ev_tr[1]));
         fs.transform_timed = false;
         sxe_timings &s = c->timing_totals;
-        s.transform_ms += t.transform_ms; s.object_ms += t.object_ms; s.setup_ms += t.setup_ms; s.scan_ms += t.scan_ms;
-        s.bin_ms += t.bin_ms; s.raster_shade_ms += t.raster_shade_ms; s.frame_ms += t.frame_ms;
+        s.transform_ms += t.transform_ms; s.object_ms += t.object_ms; s.setup_ms += t.setup_ms;
+        s.finish_ms += t.finish_ms; s.raster_shade_ms += t.raster_shade_ms; s.frame_ms += t.frame_ms;
         c->timed_frames++;
     }
     return SXE_OK;
@@ -949,7 +961,6 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
     if ((e = c->tile_counters.reserve(10 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_launch.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile launch records)", e);
-    if ((e = c->bin_start.reserve(nt)) != hipSuccess) return bail("hipMalloc(bin class offsets)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
@@ -966,7 +977,7 @@ void sxe_destroy(sxe_ctx *c)
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
     c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
-    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->bin_keys.release(); c->walk_list.release(); c->fan_order.release(); c->bin_pos.release(); c->bin_pos4.release(); c->tile_launch.release(); c->bin_start.release();
+    c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->walk_list.release(); c->fan_order.release(); c->tile_launch.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
     for (auto &img : c->images) {
@@ -1218,8 +1229,11 @@ int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
     if (k.overflow) {
         c->images[image_index].drawn = false;
         if (k.overflow & kOverflowBins)
-            return fail(c, SXE_E_CAPACITY, "frame needs %u bin entries, the static work array has room for %zu", k.total_pairs,
-                        w.bin_capacity);
+            return fail(c, SXE_E_CAPACITY,
+                        "frame needs bins of %u/%u/%u/%u/%u entries per tile (size classes 0-3, late entries), the static work "
+                        "array has room for %u/%u/%u/%u/%u",
+                        k.need[0], k.need[1], k.need[2], k.need[3], k.need[4], w.bl.cap[0], w.bl.cap[1], w.bl.cap[2], w.bl.cap[3],
+                        w.bl.cap[4]);
         return fail(c, SXE_E_CAPACITY, "frame clips %u triangles into %u fan triangles, the static work array has room for %zu",
                     k.clip_count, k.fan_records, w.fan_capacity);
     }

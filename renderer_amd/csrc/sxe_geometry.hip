@@ -6,14 +6,12 @@
 //                   clears the frame's counters
 //   k_setup         one thread per submitted triangle: vertex transform, trivial reject, perspective
 //                   divide, snap, orientation, bounding box, exact coverage test for tiny boxes;
-//                   writes one record per surviving triangle in submission order and reserves its
-//                   bin entries (per screen tile and pixel-box size class)
+//                   writes one record per surviving triangle in submission order and files it in
+//                   the bins of the (up to four) screen tiles it touches, by pixel-box size class
 //   k_clip          triangles that cross the near, far or a guard-band plane: Sutherland-Hodgman
 //                   and one record per triangle of the resulting fan
-//   k_scan          bin offsets (exclusive scan of the tile counts), totals, capacity check, launch
-//                   order of the tiles
-//   k_bin           files record slots in the per-tile bins at the reserved positions, largest size
-//                   class last in a bin; triangles over many tiles take their entries here
+//   k_finish        totals and capacity check, launch order of the tiles (dearest first), and the bin
+//                   entries of triangles that touch more than four tiles and of clipped fans
 //   k_raster_shade  (sxe_raster.hip) one workgroup per 32x32 tile
 //
 // What the kernels replace in the reference is fixed-function Vulkan state selected at
@@ -377,8 +375,6 @@ __device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
 // src/renderer/drawer.rs:700) fall out of a (depth | slot) minimum.
 struct SetupShared {
     uint32_t wave_tot[kSetupThreads / 64];
-    uint32_t keys[kSetupThreads];
-    uint32_t pos[kSetupThreads];
     union {
         // first the projected vertices of the work item's triangles: position, (z/w, 1/w), (u/w, v/w), flags
         struct {
@@ -491,10 +487,9 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // class) group of the wave; the reply is needed only when the keys are staged further down.
     const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
     const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
-    const uint32_t tile = single ? (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0 : 0xFFFFFFFFu;
     const uint32_t part = size_class((uint32_t)((st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1)), narrow(st.t));
     // A triangle that touches up to four tiles reserves an entry in each of those bins as well;
-    // larger ones are only counted and take their entries in k_bin.
+    // larger ones are only counted and take their entries in k_finish.
     const uint32_t cols_m1 = (uint32_t)(st.px1 / kTile - tx0), rows_m1 = (uint32_t)(st.py1 / kTile - ty0);
     const uint32_t n_touched = (cols_m1 + 1u) * (rows_m1 + 1u);
     const bool few = (state == FAST) && !single && n_touched <= 4u;
@@ -531,7 +526,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     }
     {
         // Triangles over more than four tiles are only counted here; their slots go on a list that
-        // k_bin spreads evenly over waves of its own (one list position per wave of this kernel
+        // k_finish spreads evenly over waves of its own (one list position per wave of this kernel
         // would leave a wave full of such triangles with all of their entries to file).
         const bool walker = state == FAST && !single && !few;
         if (walker) count_box(a, st);
@@ -566,20 +561,29 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         }
         make_records(a, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
     }
-    uint32_t reserved4[4]; // position of this lane's entry j in its bin part
+    // File the triangle: its slot number goes to the reserved position of the size class's region
+    // in the bin of every tile it touches (up to four; larger ones are on the walk list).
+    {
+        const uint32_t first = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+        const uint32_t cap = pick_region(a.bl.cap, part), off = pick_region(a.bl.off, part);
+        bool over = false;
+        uint32_t cx = 0, cy = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) reserved4[j] = (uint32_t)__shfl((int)raw4[j], (int)(who4[j] & 255u)) + (who4[j] >> 8);
-    const uint32_t bin_pos = reserved4[0];
-    if (few) a.bin_pos4[slot] = make_uint4(reserved4[0], reserved4[1], reserved4[2], reserved4[3]);
+        for (int j = 0; j < 4; ++j) {
+            const bool has = (j == 0 && single) || (few && (uint32_t)j < n_touched);
+            const uint32_t at = (uint32_t)__shfl((int)raw4[j], (int)(who4[j] & 255u)) + (who4[j] >> 8);
+            if (has) {
+                if (at < cap)
+                    a.bins[(first + cy * a.g.tiles_x + cx) * a.bl.stride + off + at] = slot;
+                else
+                    over = true;
+            }
+            if (++cx > cols_m1) { cx = 0; ++cy; }
+        }
+        if (__ballot(over) && lane == 0) atomicOr(&a.counters->overflow, kOverflowBins);
+    }
     // (the rank barrier above came after the last read of the vertex arrays, which `stage` overlays)
     if (state != CULLED) {
-        sh.pos[local] = bin_pos;
-        const uint32_t cols = cols_m1, rows = rows_m1;
-        const uint32_t block_key = (cols < 16u && rows < 16u)
-                                       ? kBinKeyBlock | (part << 28) | (rows << 24) | (cols << 20) |
-                                             ((uint32_t)(ty0 - (int32_t)a.g.tile_row0) << 8) | (uint32_t)tx0
-                                       : kBinKeyFromRecord;
-        sh.keys[local] = state == CLIP ? kBinKeyNone : (single ? tile * 4u + part : block_key);
         uint4 *sr = sh.stage, *ss = sh.stage + 2 * kSetupThreads; // raster records, then shading records
         sr[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
         sr[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), __float_as_uint(r.rA));
@@ -588,10 +592,6 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         ss[3 * local + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_or_ra, h.tex_fan);
     }
     __syncthreads();
-    if ((uint32_t)tid < total) {
-        a.bin_keys[slot0 + tid] = sh.keys[tid];
-        a.bin_pos[slot0 + tid] = sh.pos[tid];
-    }
     {
         // (total <= 256: at most two and three 16-byte pieces per thread)
         uint4 *dst = reinterpret_cast<uint4 *>(a.rast + slot0);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// Scan
+// Finish: totals, launch order, late bin entries
 // ------------------------------------------------------------------------------------------
 
 __device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
@@ -709,44 +709,24 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v, int lane)
     return v;
 }
 
-__device__ inline unsigned long long wave_inclusive_scan64(unsigned long long v, int lane)
-{
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long y = __shfl_up(v, d);
-        if (lane >= d) v += y;
-    }
-    return v;
-}
-
 constexpr int kOrderClasses = 128;
 __device__ inline uint32_t order_class(uint32_t count) { return min((count + 15u) >> 4, (uint32_t)kOrderClasses - 1u); }
 
-__device__ inline uint32_t bin_size(const ScanArgs &a, uint32_t i)
-{
-    return bin_size(a.tiles[i]);
-}
-
 // Expected running time of a tile's workgroup, in units of one small-box entry: measured tile
-// durations fit 1 : 3.3 : 100 for entries with small boxes, larger boxes, and triangles that span
-// more than four tiles.
-__device__ inline uint32_t tile_cost(const ScanArgs &a, uint32_t i)
+// durations fit 1 : 1 : 2 : 8 for the four size classes and 100 for a late entry.
+__device__ inline uint32_t tile_cost(const TileCtr &t)
 {
-    const TileCtr t = a.tiles[i];
     return (t.cnt[0] + t.cnt[1] + 2u * t.cnt[2] + 8u * t.cnt[3] + 100u * t.multi) >> 2;
 }
 
-// Tiles are handled in chunks of 8192 (eight per thread).  With C chunks the grid is
-//   workgroup 0:        total number of surviving triangles;
-//   workgroups 1..C:    bin sizes of a chunk's tiles, their exclusive scan and the per-class offsets;
-//   workgroups C+1..2C: launch order of a chunk's tiles.
-// A workgroup works out what the chunks before its own contribute by itself (their sizes, their
-// class histogram), which costs one more coalesced pass over the counters and no synchronisation
-// between workgroups.
-constexpr uint32_t kScanChunk = 8192;
+// Tiles are ordered in chunks of 4096 (eight per thread), one workgroup per chunk.  A workgroup
+// works out what the other chunks contribute by itself (their class histogram), which costs one
+// more coalesced pass over the counters and no synchronisation between workgroups.
+constexpr uint32_t kOrderChunk = 4096;
+constexpr uint32_t kFinishThreads = 512;
 
 // Sums are kept in 64 bits: a frame inside the stated limits can hold more than 2^32 (triangle,
-// tile) pairs (a few ten thousand screen-filling triangles on an 8K frame), and a total that wrapped
-// would pass the capacity check.
+// tile) pairs (a few ten thousand screen-filling triangles on an 8K frame).
 __device__ inline unsigned long long block_sum(unsigned long long v, unsigned long long *s_part, int lane, int wave)
 {
     for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
@@ -754,8 +734,19 @@ __device__ inline unsigned long long block_sum(unsigned long long v, unsigned lo
     if (lane == 0) s_part[wave] = v;
     __syncthreads();
     unsigned long long tot = 0;
-    for (int w = 0; w < 16; ++w) tot += s_part[w];
+    for (int w = 0; w < (int)kFinishThreads / 64; ++w) tot += s_part[w];
     return tot;
+}
+
+__device__ inline uint32_t block_max(uint32_t v, unsigned long long *s_part, int lane, int wave)
+{
+    for (int d = 32; d; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    __syncthreads();
+    if (lane == 0) s_part[wave] = v;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int w = 0; w < (int)kFinishThreads / 64; ++w) m = max(m, (uint32_t)s_part[w]);
+    return m;
 }
 
 // counter[cls] += 1 for every lane with `on`; returns the value before the lane's own increment.
@@ -776,148 +767,8 @@ __device__ inline uint32_t class_take(uint32_t *counter, uint32_t cls, bool on, 
     return at;
 }
 
-__global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
-{
-    __shared__ unsigned long long s_part[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t last_tile = max(a.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
-    const uint32_t chunks = max((a.n_tiles + kScanChunk - 1u) / kScanChunk, 1u);
-    if (blockIdx.x == 0) {
-        // four counts per load, four loads in flight per thread
-        uint32_t sum = 0;
-        const uint32_t n4 = a.n_blocks / 4u;
-        const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
-        for (uint32_t i = tid; i < n4; i += 4096) {
-            uint4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (i + 1024u * k < n4) ? c4[i + 1024u * k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        }
-        if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
-        const uint32_t tot = (uint32_t)block_sum(sum, s_part, lane, wave); // (at most 256 per work item, 2^23 work items)
-        if (tid == 0) a.counters->total_records = tot;
-        return;
-    }
-    if (blockIdx.x > chunks) {
-        // launch order of the tile workgroups: a counting sort by estimated cost, dearest first, so
-        // that the long-running tiles start early and the short ones fill the end of the launch
-        const uint32_t chunk = blockIdx.x - chunks - 1u, base = chunk * kScanChunk;
-        __shared__ uint32_t s_hist[kOrderClasses], s_before[kOrderClasses];
-        if (tid < kOrderClasses) s_hist[tid] = s_before[tid] = 0;
-        __syncthreads();
-        uint32_t mine[8]; // classes of this chunk's tiles: the counters are read once
-#pragma unroll
-        for (int k = 0; k < 8; ++k) mine[k] = order_class(tile_cost(a, min(base + (uint32_t)tid + 1024u * (uint32_t)k, last_tile)));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) class_take(s_hist, mine[k], base + (uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles, lane);
-        // the other chunks: every tile counts for the class sizes, the earlier ones also for this
-        // chunk's place inside each class
-        for (uint32_t other = 0; other < chunks; ++other)
-            if (other != chunk) {
-                uint32_t cls[8]; // (all eight loads in flight together)
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    cls[k] = order_class(tile_cost(a, min(other * kScanChunk + (uint32_t)tid + 1024u * (uint32_t)k, last_tile)));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool on = other * kScanChunk + (uint32_t)tid + 1024u * (uint32_t)k < a.n_tiles;
-                    class_take(s_hist, cls[k], on, lane);
-                    if (other < chunk) class_take(s_before, cls[k], on, lane);
-                }
-            }
-        __syncthreads();
-        if (wave == 0) {
-            // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
-            static_assert(kOrderClasses == 128, "two classes per lane of one wave");
-            const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
-            const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
-            s_hist[kOrderClasses - 1 - 2 * lane] = before + s_before[kOrderClasses - 1 - 2 * lane];
-            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0 + s_before[kOrderClasses - 2 - 2 * lane];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + (uint32_t)tid + 1024u * (uint32_t)k;
-            const uint32_t at = class_take(s_hist, mine[k], i < a.n_tiles, lane);
-            if (i < a.n_tiles) a.tile_order[at] = i;
-        }
-        return;
-    }
-    // Bin offsets of one chunk.  Sizes go through LDS so that both the loads of the counters and
-    // the stores of the offsets run along consecutive tiles in consecutive lanes, all of a
-    // thread's loads in flight at once.
-    __shared__ uint32_t s_size[kScanChunk];
-    const uint32_t chunk = blockIdx.x - 1u, base = chunk * kScanChunk;
-    TileCtr mine[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + 1024u * k, last_tile)];
-    // what the bins of the earlier chunks take
-    unsigned long long earlier = 0;
-    for (uint32_t i = tid; i < base; i += 8192) { // (base is a multiple of 8192: no bounds to check)
-        uint32_t sz[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sz[k] = bin_size(a, i + 1024u * k);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) earlier += sz[k];
-    }
-    const unsigned long long carry = block_sum(earlier, s_part, lane, wave);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s_size[tid + 1024 * k] = (base + (uint32_t)tid + 1024u * k < a.n_tiles) ? bin_size(mine[k]) : 0u;
-    __syncthreads();
-    uint32_t v[8];
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        v[k] = s_size[8 * tid + k];
-        sum += v[k];
-    }
-    const unsigned long long incl = wave_inclusive_scan64(sum, lane);
-    __syncthreads(); // (block_sum's s_part has been read by everybody)
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    unsigned long long wbase = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const unsigned long long p = s_part[w];
-        if (w < wave) wbase += p;
-        tot += p;
-    }
-    // (offsets are used only when the total fits the bin array, which holds fewer than 2^32 entries)
-    uint32_t run = (uint32_t)(carry + wbase + incl - sum);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s_size[8 * tid + k] = run; // the tile's offset from here on
-        run += v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t i = base + (uint32_t)tid + 1024u * k;
-        const uint32_t off = s_size[tid + 1024 * k], c0 = mine[k].cnt[0], c1 = mine[k].cnt[1], c2 = mine[k].cnt[2];
-        if (i < a.n_tiles) a.bin_start[i] = make_uint4(off, off + c0, off + c0 + c1, off + c0 + c1 + c2);
-    }
-    if (tid == 0 && chunk + 1u == chunks) {
-        const unsigned long long total = carry + tot;
-        a.counters->total_pairs = (uint32_t)min(total, 0xFFFFFFFFull);
-        if (total > a.bin_capacity) atomicOr(&a.counters->overflow, kOverflowBins);
-        if (total > 0xFFFFFFFFull) atomicOr(&a.counters->overflow, kOverflowPairs); // no bin array can hold this frame
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Binning
-// ------------------------------------------------------------------------------------------
-
-// Scatters the slot numbers of the surviving triangles into the tile bins.  The order of entries
-// inside a bin is irrelevant to the image; they are laid out by size class so that the tile kernel
-// meets boxes of similar size next to each other.
-// Triangles that touch up to four tiles come with their positions inside the size class of each
-// bin (reserved by k_setup): filing them is one store per tile.  Triangles that span more tiles
-// take one entry behind the reserved ones of each of those bins here.  A key is a kBinKey* value
-// or 4 * tile + size class.
-
 // Block of tiles a triangle's pixel box touches, from its raster record.
-__device__ inline bool block_from_record(const BinArgs &a, uint32_t rec, uint32_t &cols, uint32_t &rows, uint32_t &first)
+__device__ inline bool block_from_record(const FinishArgs &a, uint32_t rec, uint32_t &cols, uint32_t &rows, uint32_t &first)
 {
     const RastRec r = a.rast[rec];
     int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
@@ -930,74 +781,11 @@ __device__ inline bool block_from_record(const BinArgs &a, uint32_t rec, uint32_
     return true;
 }
 
-// The block of tiles a kBinKeyBlock key names.
-struct KeyBlock {
-    uint32_t cols, rows, first, part;
-};
-__device__ inline bool is_block_key(uint32_t key) { return (key & 0xC0000000u) == kBinKeyBlock; }
-__device__ inline KeyBlock decode_block(const BinArgs &a, uint32_t key)
-{
-    KeyBlock b;
-    b.cols = ((key >> 20) & 15u) + 1u;
-    b.rows = ((key >> 24) & 15u) + 1u;
-    b.first = ((key >> 8) & 255u) * a.g.tiles_x + (key & 255u);
-    b.part = (key >> 28) & 3u;
-    return b;
-}
-
-// Filing is split into its loads and its stores: the stores of one group of 64 slots must not sit
-// between the loads of the next (the compiler cannot tell that bins and tables do not overlap, so
-// it would wait for every group's round trip in turn).  What the loads bring:
-struct BinLoads {
-    uint32_t start;   // single tile: first entry of the triangle's size class in that bin
-    uint4 p4;         // two to four tiles: the positions k_setup reserved
-    uint32_t st[4];   //   and where the size class starts in each of those bins
-};
-
-__device__ inline BinLoads bin_gather(const BinArgs &a, bool valid, uint32_t rec, uint32_t key)
-{
-    BinLoads g;
-    g.start = 0;
-    g.p4 = make_uint4(0, 0, 0, 0);
-    g.st[0] = g.st[1] = g.st[2] = g.st[3] = 0;
-    if (valid && key < kBinKeyBlock) g.start = a.bin_start[key];
-    if (a.debug & kDebugSkipLarge) return g; // development: single-tile triangles only
-    if (valid && is_block_key(key)) {
-        const KeyBlock b = decode_block(a, key);
-        if (b.cols * b.rows <= 4u) {
-            g.p4 = a.bin_pos4[rec];
-            uint32_t cx = 0, cy = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((uint32_t)j < b.cols * b.rows) {
-                    g.st[j] = a.bin_start[4u * (b.first + cy * a.g.tiles_x + cx) + b.part];
-                    if (++cx == b.cols) { cx = 0; ++cy; }
-                }
-        }
-    }
-    return g;
-}
-
-__device__ inline void bin_store(const BinArgs &a, bool valid, uint32_t rec, uint32_t key, uint32_t p, const BinLoads &g)
-{
-    if (valid && key < kBinKeyBlock) a.bins[g.start + p] = rec;
-    if (a.debug & kDebugSkipLarge) return;
-    uint32_t n_few = 0;
-    if (valid && is_block_key(key)) {
-        const KeyBlock b = decode_block(a, key);
-        n_few = b.cols * b.rows <= 4u ? b.cols * b.rows : 0u;
-    }
-    const uint32_t given[4] = {g.p4.x, g.p4.y, g.p4.z, g.p4.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if ((uint32_t)j < n_few) a.bins[g.st[j] + given[j]] = rec;
-}
-
-// Triangles over more than four tiles take one entry behind the reserved ones of each bin they
-// touch.  All (triangle, tile) pairs of the wave are dealt out over its lanes, 64 per round, so a
-// round costs one chain of memory round trips however many triangles are involved.  Every lane of
-// the wave must call this.
-__device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint32_t cols, uint32_t rows, uint32_t first)
+// Triangles over more than four tiles (and fan triangles) take one entry in the late region of
+// each bin they touch.  All (triangle, tile) pairs of the wave are dealt out over its lanes, 64
+// per round, so a round costs one chain of memory round trips however many triangles are involved.
+// Every lane of the wave must call this.
+__device__ inline void bin_walk(const FinishArgs &a, bool walk, uint32_t rec, uint32_t cols, uint32_t rows, uint32_t first)
 {
     const unsigned long long todo = __ballot(walk);
     if (!todo) return;
@@ -1006,6 +794,8 @@ __device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint3
     uint32_t total = 0;
     for (unsigned long long m = todo; m; m &= m - 1)
         total += (uint32_t)__builtin_amdgcn_readlane((int)n_items, __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1));
+    const uint32_t cap = a.bl.cap[kSizeClasses], off = a.bl.off[kSizeClasses];
+    bool over = false;
     for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t i = base + (uint32_t)lane;
         uint32_t owner = 0, local = 0, acc = 0;
@@ -1023,105 +813,154 @@ __device__ inline void bin_walk(const BinArgs &a, bool walk, uint32_t rec, uint3
         if (i < total) {
             const uint32_t cy = local / w_cols, cx = local - cy * w_cols;
             const uint32_t tl = w_first + cy * a.g.tiles_x + cx;
-            a.bins[a.bin_start[4u * tl + 3u] + a.tiles[tl].cnt[3] + atomicAdd(&a.late_fill[tl], 1u)] = w_rec;
+            const uint32_t at = atomicAdd(&a.late_fill[tl], 1u);
+            if (at < cap)
+                a.bins[tl * a.bl.stride + off + at] = w_rec;
+            else
+                over = true;
         }
     }
+    if (__ballot(over) && lane == 0) atomicOr(&a.counters->overflow, kOverflowBins);
 }
 
-// A wave files the survivors of one setup work item (their keys were written by k_setup); the
-// workgroups past the last work item take the listed triangles that span more than four tiles and
-// the fan triangles of clipped primitives.
-constexpr uint32_t kWalkChunk = 16;
-template <bool DEV>
-__global__ __launch_bounds__(kSetupThreads) void k_bin(BinArgs a)
+// What a tile's counters add to the frame's totals.
+struct TileTotals {
+    unsigned long long pairs;
+    uint32_t need[kBinRegions];
+};
+__device__ inline void account(TileTotals &tt, const TileCtr &t, bool on)
 {
-    if (!DEV) a.debug = 0u;
+    if (!on) return;
+    tt.pairs += (unsigned long long)bin_reserved(t) + t.multi;
+#pragma unroll
+    for (int r = 0; r < kSizeClasses; ++r) tt.need[r] = max(tt.need[r], t.cnt[r]);
+    tt.need[kSizeClasses] = max(tt.need[kSizeClasses], t.multi);
+}
+
+// Grid (C = chunks of 4096 tiles):
+//   workgroup 0:           number of surviving triangles;
+//   workgroups 1..C:       launch order of a chunk's tiles and their launch records; the first of
+//                          them also the frame's totals: bin entries, the fullest region of each kind
+//                          over all tiles (what the bins would need), capacity check;
+//   workgroups C+1..:      the late entries, the listed triangles dealt out over all waves, so that
+//                          the dependent memory round trips of a crowd of them (a mesh close to the
+//                          camera) are spread out instead of queueing up in one wave.
+constexpr uint32_t kWalkChunk = 16;
+__global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
+{
+    __shared__ unsigned long long s_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t seg_groups = (a.n_blocks + 3u) / 4u;
-    const uint32_t seg = blockIdx.x * 4u + (uint32_t)wave;
-    const bool filing = blockIdx.x < seg_groups && seg < a.n_blocks;
-    // A wave's work is a chain of dependent loads.  Its first link asks for everything whose
-    // address is known: the overflow flag, the segment's count and, without waiting for the count,
-    // the first kEager * 64 keys and positions (values past the count are stale and ignored).
-    constexpr int kEager = 2;
-    uint32_t cnt_v = 0, keys[kSetupThreads / 64], pos[kSetupThreads / 64];
+    const uint32_t last_tile = max(a.g.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
+    const uint32_t chunks = max((a.g.n_tiles + kOrderChunk - 1u) / kOrderChunk, 1u);
+    if (blockIdx.x == 0) {
+        // four counts per load, sixteen loads in flight per thread
+        uint32_t sum = 0;
+        const uint32_t n4 = a.n_blocks / 4u;
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
+        for (uint32_t i = tid; i < n4; i += 16u * kFinishThreads) {
+            uint4 v[16];
 #pragma unroll
-    for (int k = 0; k < kEager; ++k) {
-        keys[k] = kBinKeyNone;
-        pos[k] = 0;
+            for (int k = 0; k < 16; ++k) v[k] = (i + kFinishThreads * k < n4) ? c4[i + kFinishThreads * k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+        if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
+        const uint32_t records = (uint32_t)block_sum(sum, s_part, lane, wave); // (at most 256 per work item, 2^23 work items)
+        if (tid == 0) a.counters->total_records = records;
+        return;
     }
-    if (filing) {
-        cnt_v = a.blk_count[seg];
+    if (blockIdx.x <= chunks) {
+        // launch order of the tile workgroups: a counting sort by estimated cost, dearest first, so
+        // that the long-running tiles start early and the short ones fill the end of the launch
+        const uint32_t chunk = blockIdx.x - 1u, base = chunk * kOrderChunk;
+        __shared__ uint32_t s_hist[kOrderClasses], s_before[kOrderClasses];
+        if (tid < kOrderClasses) s_hist[tid] = s_before[tid] = 0;
+        __syncthreads();
+        TileTotals tt;
+        tt.pairs = 0;
 #pragma unroll
-        for (int k = 0; k < kEager; ++k) {
-            keys[k] = a.bin_keys[seg * kSetupThreads + 64u * k + (uint32_t)lane];
-            pos[k] = a.bin_pos[seg * kSetupThreads + 64u * k + (uint32_t)lane];
-        }
-    }
-    if (a.counters->overflow) return;
-    // on the side: what the tile workgroups need to start, gathered into one record per launch position
-    {
-        const uint32_t i = blockIdx.x * kSetupThreads + (uint32_t)tid;
-        if (i < a.g.n_tiles) {
-            const uint32_t tile = a.tile_order[i];
-            a.tile_launch[i] = make_uint4(tile, a.bin_start[4u * tile], bin_size(a.tiles[tile]), 0u);
-        }
-    }
-    if (blockIdx.x < seg_groups) {
-        if (!filing) return;
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
-        if (cnt == 0) return;
+        for (int r = 0; r < kBinRegions; ++r) tt.need[r] = 0;
+        TileCtr mine[8]; // this chunk's tiles: their counters are read once (all eight loads in flight together)
 #pragma unroll
-        for (int k = 0; k < kEager; ++k)
-            if (64u * k + (uint32_t)lane >= cnt) keys[k] = kBinKeyNone;
+        for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
 #pragma unroll
-        for (int k = kEager; k < kSetupThreads / 64; ++k) {
-            const uint32_t i = 64u * k + (uint32_t)lane;
-            keys[k] = i < cnt ? a.bin_keys[seg * kSetupThreads + i] : kBinKeyNone;
-            pos[k] = i < cnt ? a.bin_pos[seg * kSetupThreads + i] : 0u;
+        for (int k = 0; k < 8; ++k) {
+            const bool on = base + (uint32_t)tid + kFinishThreads * (uint32_t)k < a.g.n_tiles;
+            class_take(s_hist, order_class(tile_cost(mine[k])), on, lane);
+            account(tt, mine[k], on);
         }
-        if (a.debug & kDebugSkipSmall) { // development: stop after the loads
-            if ((keys[0] ^ keys[1] ^ keys[2] ^ keys[3] ^ pos[0]) == 0x12345678u) a.bins[0] = 0;
-            return;
-        }
-        BinLoads g[kSetupThreads / 64];
+        // the other chunks: every tile counts for the class sizes and the totals, the earlier ones
+        // also for this chunk's place inside each class
+        for (uint32_t other = 0; other < chunks; ++other)
+            if (other != chunk) {
+                TileCtr oc[8];
 #pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k) {
-            const uint32_t i = 64u * k + (uint32_t)lane;
-            g[k] = bin_gather(a, i < cnt, seg * kSetupThreads + i, keys[k]);
-        }
+                for (int k = 0; k < 8; ++k) oc[k] = a.tiles[min(other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
 #pragma unroll
-        for (int k = 0; k < kSetupThreads / 64; ++k) {
-            const uint32_t i = 64u * k + (uint32_t)lane;
-            bin_store(a, i < cnt, seg * kSetupThreads + i, keys[k], pos[k], g[k]);
-        }
-    } else {
-        // Late entries.  The listed triangles are dealt out sixteen to a wave and round, so that
-        // the dependent memory round trips of a crowd of them (a mesh close to the camera) are
-        // spread over many waves instead of queueing up in one.
-        if (a.debug & (kDebugSkipLarge | kDebugSkipAtomic)) return; // development: without the late entries
-        if (blockIdx.x - seg_groups >= a.walk_blocks) return;       // (workgroups launched for the tile list only)
-        const uint32_t n_walk = a.counters->walk_count;
-        const uint32_t n_slots = a.n_blocks * kSetupThreads;
-        const uint32_t wave_id = (blockIdx.x - seg_groups) * 4u + (uint32_t)wave;
-        for (uint32_t base = wave_id * kWalkChunk; base < n_walk; base += a.walk_blocks * 4u * kWalkChunk) {
-            const bool mine = (uint32_t)lane < kWalkChunk && base + (uint32_t)lane < n_walk;
-            uint32_t rec = 0, key = kBinKeyFromRecord;
-            if (mine) {
-                rec = a.walk_list[base + (uint32_t)lane];
-                if (rec < n_slots) key = a.bin_keys[rec]; // (fan triangles have no key)
+                for (int k = 0; k < 8; ++k) {
+                    const bool on = other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k < a.g.n_tiles;
+                    const uint32_t cls = order_class(tile_cost(oc[k]));
+                    class_take(s_hist, cls, on, lane);
+                    if (other < chunk) class_take(s_before, cls, on, lane);
+                    account(tt, oc[k], on);
+                }
             }
-            uint32_t cols = 0, rows = 0, first = 0;
-            bool walk = false;
-            if (mine && is_block_key(key)) {
-                const KeyBlock b = decode_block(a, key);
-                cols = b.cols; rows = b.rows; first = b.first;
-                walk = true;
-            } else if (mine) {
-                walk = block_from_record(a, rec, cols, rows, first);
-            }
-            bin_walk(a, walk, rec, cols, rows, first);
+        __syncthreads();
+        if (wave == 0) {
+            // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
+            static_assert(kOrderClasses == 128, "two classes per lane of one wave");
+            const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
+            const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
+            s_hist[kOrderClasses - 1 - 2 * lane] = before + s_before[kOrderClasses - 1 - 2 * lane];
+            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0 + s_before[kOrderClasses - 2 - 2 * lane];
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + (uint32_t)tid + kFinishThreads * (uint32_t)k;
+            const uint32_t at = class_take(s_hist, order_class(tile_cost(mine[k])), i < a.g.n_tiles, lane);
+            if (i < a.g.n_tiles) {
+                uint4 *dst = reinterpret_cast<uint4 *>(a.tile_launch + at);
+                dst[0] = make_uint4(i, mine[k].multi, mine[k].cnt[3], mine[k].cnt[2]);
+                dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], 0u, 0u);
+            }
+        }
+        if (chunk == 0) {
+            const unsigned long long pairs = block_sum(tt.pairs, s_part, lane, wave);
+            uint32_t need[kBinRegions];
+#pragma unroll
+            for (int r = 0; r < kBinRegions; ++r) need[r] = block_max(tt.need[r], s_part, lane, wave);
+            if (tid == 0) {
+                a.counters->total_pairs = (uint32_t)min(pairs, 0xFFFFFFFFull);
+                uint32_t flags = pairs > 0xFFFFFFFFull ? kOverflowPairs | kOverflowBins : 0u; // beyond any bin array
+#pragma unroll
+                for (int r = 0; r < kBinRegions; ++r) {
+                    a.counters->need[r] = need[r];
+                    if (need[r] > a.bl.cap[r]) flags |= kOverflowBins;
+                }
+                if (flags) atomicOr(&a.counters->overflow, flags);
+            }
+        }
+        return;
+    }
+    // Late entries.  A wave takes up to sixteen listed triangles per round; when the list is short,
+    // fewer, so that all waves have work (a triangle's entries are one chain of memory round trips
+    // per 64 tiles it touches, and chains in one wave run one after the other).
+    const uint32_t wb = blockIdx.x - chunks - 1u;
+    const uint32_t n_walk = a.counters->walk_count;
+    constexpr uint32_t kWaves = kFinishThreads / 64;
+    const uint32_t n_waves = a.walk_blocks * kWaves;
+    const uint32_t per_wave = min(max((n_walk + n_waves - 1u) / n_waves, 1u), kWalkChunk);
+    const uint32_t wave_id = wb * kWaves + (uint32_t)wave;
+    for (uint32_t base = wave_id * per_wave; base < n_walk; base += n_waves * per_wave) {
+        const bool mine = (uint32_t)lane < per_wave && base + (uint32_t)lane < n_walk;
+        uint32_t rec = 0, cols = 0, rows = 0, first = 0;
+        bool walk = false;
+        if (mine) {
+            rec = a.walk_list[base + (uint32_t)lane];
+            walk = block_from_record(a, rec, cols, rows, first);
+        }
+        bin_walk(a, walk, rec, cols, rows, first);
     }
 }
 
@@ -1176,23 +1015,10 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_scan(const ScanArgs &a, hipStream_t s)
+hipError_t launch_finish(const FinishArgs &a, hipStream_t s)
 {
-    const uint32_t chunks = a.n_tiles > kScanChunk ? (a.n_tiles + kScanChunk - 1u) / kScanChunk : 1u;
-    hipLaunchKernelGGL(k_scan, dim3(1u + 2u * chunks), dim3(1024), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_bin(const BinArgs &a, hipStream_t s)
-{
-    // (enough workgroups for the per-tile launch records even when there is nothing to file)
-    const uint32_t filing = (a.n_blocks + 3u) / 4u + a.walk_blocks, listing = (a.g.n_tiles + kSetupThreads - 1u) / kSetupThreads;
-    const uint32_t groups = filing > listing ? filing : listing;
-    if (groups == 0) return hipSuccess;
-    if (a.debug)
-        hipLaunchKernelGGL(k_bin<true>, dim3(groups), dim3(kSetupThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_bin<false>, dim3(groups), dim3(kSetupThreads), 0, s, a);
+    const uint32_t chunks = a.g.n_tiles > kOrderChunk ? (a.g.n_tiles + kOrderChunk - 1u) / kOrderChunk : 1u;
+    hipLaunchKernelGGL(k_finish, dim3(1u + chunks + a.walk_blocks), dim3(kFinishThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -118,8 +118,9 @@ struct FrameCounters {
     uint32_t fan_records;   // fan triangles of clipped primitives
     uint32_t overflow;      // kOverflow* bits
     uint32_t clip_count;    // triangles handed to the clip kernel
-    uint32_t walk_count;    // triangles that take their bin entries in k_bin (entries of walk_list)
-    uint32_t pad[10];       // development counters (box census)
+    uint32_t walk_count;    // triangles that take their bin entries in k_finish (entries of walk_list)
+    uint32_t need[5];       // per bin region: the largest number of entries any tile has for it
+    uint32_t pad[5];        // development counters (box census)
 };
 
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
@@ -157,12 +158,27 @@ struct ObjectArgs {
     float rot_delta_ms;
 };
 
-// Per-tile bookkeeping of a frame.  A tile's bin is a range of bin_size entries of the bin array
-// (k_scan works out where it starts), laid out by pixel-box size so that the lanes of a wave of
-// the tile kernel walk boxes of similar size: first the entries of size class 0, then class 1, 2,
-// 3 (all reserved by k_setup, cnt[] of them), then the `multi` entries that k_bin places itself
-// (triangles touching more than four tiles, fans of clipped triangles).
+// Per-tile bookkeeping of a frame.  Every tile owns `stride` consecutive entries of the bin array,
+// cut into five regions whose capacities are the same for every tile: one per pixel-box size class,
+// filled by k_setup itself (a wave reserves positions with one atomic per (tile, class) group of
+// its triangles and stores the slot numbers there), and one for the late entries (triangles
+// touching more than four tiles, fans of clipped triangles) that k_finish places.  Keeping the
+// classes apart lets the lanes of a wave of the tile kernel walk boxes of similar size.  A frame
+// that needs more room in some region than its capacity reports an overflow and is drawn again
+// with larger regions.
 constexpr int kSizeClasses = 4;
+constexpr int kBinRegions = kSizeClasses + 1;
+struct BinLayout {
+    uint32_t cap[kBinRegions]; // entries a tile can hold per region (classes 0-3, late)
+    uint32_t off[kBinRegions]; // where the region starts inside the tile's stride
+    uint32_t stride;
+};
+// cap[r] / off[r] for a region number that is not known at compile time, by selects (indexing a
+// kernel argument with a register would put the whole structure into scratch memory)
+__host__ __device__ inline uint32_t pick_region(const uint32_t (&v)[kBinRegions], uint32_t r)
+{
+    return r == 0u ? v[0] : r == 1u ? v[1] : r == 2u ? v[2] : r == 3u ? v[3] : v[4];
+}
 struct __attribute__((aligned(16))) TileCtr {
     uint32_t cnt[kSizeClasses];
     uint32_t multi, pad0, pad1, pad2;
@@ -190,8 +206,8 @@ struct SetupArgs {
     FrameGeom g;
     uint32_t *blk_count;       // survivors per workgroup
     TileCtr *tiles;
-    uint32_t *bin_pos;         // per order slot of a single-tile triangle: its reserved position
-    uint4 *bin_pos4;           // per order slot of a triangle touching 2-4 tiles: its position in each bin's back
+    uint32_t *bins;
+    BinLayout bl;
     RastRec *rast;
     WideRec *wide;
     ShadeRec *shade;
@@ -199,55 +215,39 @@ struct SetupArgs {
     uint32_t fan_capacity;     // records available past slot 256 * n_blocks; also the clip list's length
     uint32_t clip_off;         // the clip kernel does not follow: a triangle that needs it voids the frame
     ClipItem *clip_list;
-    uint32_t *bin_keys;        // per order slot: where k_bin files the triangle (kBinKey*)
     uint32_t *fan_order;       // per fan record (slot - 256 * n_blocks): the order slot of its primitive
     uint32_t *walk_list;       // slots of the triangles over more than four tiles and of the fan triangles
     FrameCounters *counters;
 };
 
-// Bin keys: 4 * tile + size class for a triangle whose box lies in one tile.
-// A triangle whose box spans a block of at most 16 x 16 tiles: kBinKeyBlock | size class << 28 |
-// (rows - 1) << 24 | (columns - 1) << 20 | first tile row (of the rendered rows) << 8 | first column.
-constexpr uint32_t kBinKeyBlock = 0x80000000u;
-constexpr uint32_t kBinKeyFromRecord = 0xFFFFFFFFu; // larger blocks and fans: k_bin derives the tiles from the record
-constexpr uint32_t kBinKeyNone = 0xFFFFFFFEu;       // the slot only ranks a clipped triangle
-
-struct ScanArgs {
-    const uint32_t *blk_count;
-    uint32_t n_blocks;
-    const TileCtr *tiles;      // counts as k_setup and k_clip left them
-    uint4 *bin_start;          // out, per tile: first bin entry of each of its four size classes
-    uint32_t *tile_order;      // tiles in launch order: fullest bins first
-    uint32_t n_tiles;
-    uint32_t bin_capacity;
-    FrameCounters *counters;
+// What a tile's workgroup needs to start, one record per launch position (dearest tiles first).
+struct __attribute__((aligned(16))) TileLaunch {
+    uint32_t tile;
+    uint32_t late, c3, c2, c1, c0; // entries per region, in the order the tile kernel takes them
+    uint32_t pad0, pad1;
 };
 
-struct BinArgs {
+struct FinishArgs {
     FrameGeom g;
     const uint32_t *blk_count;
     uint32_t n_blocks;
     uint32_t walk_blocks;      // workgroups launched for the late entries (walk_list)
     const RastRec *rast;
     const WideRec *wide;
-    const uint32_t *bin_keys;
-    const uint32_t *walk_list; // slots whose triangles take their entries here, counters->walk_count of them
-    const uint32_t *bin_pos;
-    const uint4 *bin_pos4;
-    const TileCtr *tiles;
-    const uint32_t *bin_start; // [4 * tile + size class]: first bin entry of the class (from k_scan)
-    uint32_t *late_fill;       // per tile: how many of its `multi` entries have been placed
-    const uint32_t *tile_order;
-    uint4 *tile_launch;        // per launch position: tile, bin offset, bin size
+    const uint32_t *walk_list; // records whose triangles take their entries here, counters->walk_count of them
+    const TileCtr *tiles;      // counts as k_setup and k_clip left them
+    uint32_t *late_fill;       // per tile: how many of its late entries have been placed
+    TileLaunch *tile_launch;   // out
     uint32_t *bins;
-    const FrameCounters *counters;
-    uint32_t debug;            // kDebug* switches (development only; need kDebugSkipRaster as well)
+    BinLayout bl;
+    FrameCounters *counters;
 };
 
 struct RasterArgs {
     FrameGeom g;
-    const uint4 *tile_launch;   // workgroup b renders tile tile_launch[b].x; .y bin offset, .z bin size
+    const TileLaunch *tile_launch; // workgroup b renders tile tile_launch[b].tile
     const uint32_t *bins;
+    BinLayout bl;
     const RastRec *rast;
     const WideRec *wide;
     const ShadeRec *shade;
@@ -282,8 +282,7 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
                          float4 *clip, hipStream_t s);
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
 hipError_t launch_clip(const SetupArgs &a, hipStream_t s);
-hipError_t launch_scan(const ScanArgs &a, hipStream_t s);
-hipError_t launch_bin(const BinArgs &a, hipStream_t s);
+hipError_t launch_finish(const FinishArgs &a, hipStream_t s);
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s);
 
 } // namespace sxe

@@ -488,7 +488,8 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     // launch record, its share of the tables -- and the flag is acted on behind the first barrier,
     // when all of it has arrived: one round trip to memory instead of two.
     const uint32_t overflow = a.counters->overflow;
-    const uint4 launch = a.tile_launch[blockIdx.x]; // tile, bin offset, bin size
+    const uint4 launch = reinterpret_cast<const uint4 *>(a.tile_launch)[2 * blockIdx.x];     // tile; entries: late, class 3, 2
+    const uint4 launch2 = reinterpret_cast<const uint4 *>(a.tile_launch)[2 * blockIdx.x + 1]; // class 1, 0
     static_assert(kEncPadded / 4 <= 2 * kRasterThreads, "two table pieces per thread");
     const uint4 enc_a = g_srgb_encode[tid], enc_b = g_srgb_encode[min(tid + kRasterThreads, kEncPadded / 4 - 1)];
     const float dec = c_srgb_decode[tid];
@@ -513,9 +514,19 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
-    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y);
-    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z);
-    // the bin is laid out by box size: the 64 consecutive entries a wave takes are of similar size
+    // The tile's entries are taken region by region, largest boxes first (late entries, then size
+    // class 3 down to 0): the 64 consecutive entries a wave takes are of similar size, and the quick
+    // ones fill the gaps at the end.  Entry e of that sequence lies in the region whose running
+    // total first exceeds e.
+    const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y);        // late
+    const uint32_t e2 = e1 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z);   // + class 3
+    const uint32_t e3 = e2 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.w);   // + class 2
+    const uint32_t e4 = e3 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.x);  // + class 1
+    const uint32_t e5 = e4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.y);  // + class 0
+    const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : e5;
+    const uint32_t *bin = a.bins + (size_t)tile * a.bl.stride;
+    // start of each region minus the entries taken before it
+    const uint32_t o4 = a.bl.off[4], o3 = a.bl.off[3] - e1, o2 = a.bl.off[2] - e2, o1 = a.bl.off[1] - e3, o0 = a.bl.off[0] - e4;
     {
         const uint32_t lo = 0u, hi = n;
         // a wave takes kEntriesPerLane * 64 consecutive entries per round: all their slot numbers
@@ -526,8 +537,8 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
           for (int k = 0; k < kEntriesPerLane; ++k) {
               const uint32_t e = base + (uint32_t)(kRasterThreads * k + tid);
-              // from the end of the bin: the largest boxes first, the quick ones fill the gaps
-              slots[k] = e < hi ? a.bins[off + (hi - 1u - e)] : 0xFFFFFFFFu;
+              const uint32_t at = e + (e < e1 ? o4 : e < e2 ? o3 : e < e3 ? o2 : e < e4 ? o1 : o0);
+              slots[k] = e < hi ? bin[at] : 0xFFFFFFFFu;
           }
 #pragma unroll
           for (int k = 0; k < kEntriesPerLane; ++k) {
