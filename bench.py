@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the raster/shade hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--mode frames|sortfirst] [--config 3]
+  python bench.py --gpus N --steps K --warmup W [--mode sortfirst|frames] [--config 3|4]
 
 Workload (config 3 of BASELINE.json): 10,000 instances of a 1,024-triangle mesh = 10.24 M
 triangles, 3840x2160, with the per-frame ECS rotation update running on the device.  One step is
 one pass of the hot path: rotation system -> camera -> draw of one frame, inputs resident in HBM.
+--config 4 is the same scene at 7680x4320.
 
 N > 1 (one process per GPU, launched by torch.distributed.run):
-  frames     (default) frame-parallel: rank r renders animation frames r, r+N, ...; every rank
-             advances the replicated rotation state through all frames; no data-path collective.
-             One step = N frames.  Weak scaling.
-  sortfirst  each frame is cut into N bands of whole tile rows; geometry is replicated; the
-             finished bands are gathered on rank 0 over RCCL.  One step = 1 frame.  Strong scaling.
+  sortfirst  (default) each frame is cut into N bands of whole tile rows; geometry is replicated;
+             the finished bands are gathered on rank 0 over RCCL (grouped send/receive, every band
+             at its own size) while the next frame is being drawn.  One step = 1 frame.  Strong
+             scaling: the metric BASELINE.json names.
+  frames     frame-parallel: rank r renders animation frames r, r+N, ...; every rank advances the
+             replicated rotation state through all frames; no data-path collective.  One step = N
+             frames.  Weak scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,42 +35,73 @@ SEED = 3
 DELTA_MS = 16.0
 
 
-def algorithmic_bytes(stats, width, height, covered_px, texture_bytes):
+def algorithmic_bytes(stats, scene, width, rows, covered_px):
     """Per-kernel algorithmic bytes of one frame.
 
-    setup (k_setup does the vertex stage and the triangle setup in one launch):
-        48 B per instance vertex + 60 B per submitted triangle + 32 B per surviving triangle
-    raster_shade: 32 B per surviving triangle + 8 B per pixel + texel lower bound
-    object: one 64-B model matrix in, one 64-B PVM out per object
+    raster_shade: 32 B per surviving triangle (its raster record) + 8 B per pixel (depth and colour,
+        written once) + the texel lower bound min(16 B per covered pixel, all texture bytes).
+    setup (vertex stage and triangle setup in one launch), counted for what this build moves: every
+        mesh once (shared by its instances), one 64-B matrix per object, per surviving triangle its
+        two records (32 + 48 B), 4 B per bin entry.  The per-unit figures for an engine that stores
+        one vertex copy per object and passes clip positions through memory (48 B per instance
+        vertex + 60 B per submitted triangle + 32 B per survivor) are reported beside it as
+        `expanded_buffers_bytes`: they describe traffic this build does not have.
     """
     t, tv, vi = stats["prims"], stats["records"], stats["instance_vertices"]
-    texel = min(covered_px * 16, texture_bytes)
+    tex_bytes = sum(int(x.nbytes) for x in scene.textures)
+    texel = min(covered_px * 16, tex_bytes)
+    mesh_bytes = int(scene.vertices.nbytes) + int(scene.indices.nbytes)
     return {
-        "setup": vi * 48 + t * 60 + tv * 32,
-        "raster_shade": tv * 32 + width * height * 8 + texel,
-        "object": stats["objects"] * (64 + 64),
+        "setup": mesh_bytes + stats["objects"] * 64 + tv * (32 + 48) + stats["bin_entries"] * 4,
+        "setup_expanded_buffers": vi * 48 + t * 60 + tv * 32,
+        "raster_shade": tv * 32 + width * rows * 8 + texel,
     }
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, width, height, n_prims):
-    """The CPU oracle (band-parallel variant) on one full frame of the same workload."""
+    """The CPU oracle (band-parallel variant): rotation update + one full frame per step of the
+    same workload, on the host cores this process may use."""
     from oracle import oracle
     oracle.build()
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-    models = oracle.to_model(scene.transforms)
+    # the box reports every CPU of the machine; OMP_NUM_THREADS carries this job's share of them
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = min(os.cpu_count() or 1, share) if share > 0 else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 256))
     view, proj = oracle.camera(scene.camera, width, height)
+    transforms = scene.transforms.copy()
     t0 = time.perf_counter()
     frames = 0
     while True:
-        oracle.render(scene, models, view, proj, width, height, threads=cores)
+        oracle.rotation_system(transforms, SEED, frames, DELTA_MS)
+        oracle.render(scene, oracle.to_model(transforms), view, proj, width, height, threads=cores)
         frames += 1
         dt = time.perf_counter() - t0
         if dt > 12.0 or frames >= 64:
             break
     return {"value": n_prims * frames / dt, "unit": "triangles/s", "cores": cores, "kind": "port",
-            "sample": "%d full frame(s) of the same scene and camera (frame 0 pose), %.1f s of CPU work, "
-                      "band-parallel oracle with %d threads" % (frames, dt, cores),
+            "cpu": cpu_model(), "cpus_visible": os.cpu_count(),
+            "sample": "%d step(s) of the same workload (rotation update, model matrices, one full frame each), %.1f s "
+                      "of CPU work, band-parallel oracle with %d threads (this job's share of the host: "
+                      "OMP_NUM_THREADS)" % (frames, dt, cores),
             "ms_per_frame": 1e3 * dt / frames}
+
+
+def profile_file(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -75,11 +109,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["frames", "sortfirst"], default="frames")
-    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--mode", choices=["sortfirst", "frames"], default="sortfirst")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the last frame with the oracle (slow)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="with one GPU: go through the sort-first gather pipeline anyway (its band is the whole frame)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,12 +140,15 @@ def main():
     scene = scenes.config_scene(args.config, scale=args.scale)
     width, height = scene.size
     n_prims = scene.n_triangles
-    sortfirst = args.mode == "sortfirst" and world > 1
+    sortfirst = (args.mode == "sortfirst" and world > 1) or (world == 1 and args.pipeline)
     scissor = shard.band_rows(height, world, rank) if sortfirst else None
+    if sortfirst and scissor[1] <= scissor[0]:
+        sys.exit("rank %d has no tile row to render (%d ranks for %d rows)" % (rank, world, height))
 
     drawer = api.HipDrawer(width, height, device=local_rank, n_images=2, scissor=scissor, timing=True)
     drawer.update_scene(scene)
     drawer.update_camera(scene.camera)
+    pipe = shard.SortFirstPipeline(drawer, height, width, world, rank) if sortfirst else None
 
     frame_no = [0]
 
@@ -126,13 +165,14 @@ def main():
                 drawer.rotation_system(SEED, frame_no[0], DELTA_MS, n_frames=target - frame_no[0] + 1)
                 frame_no[0] = target + 1
         drawer.update_camera(scene.camera)
-        drawer.draw(i & 1)
-        if sortfirst:
-            drawer.sync()
-            y0, y1 = scissor
-            shard.gather_bands(shard.band_tensor(drawer, i & 1, y0, y1), height, width, world, rank)
+        if pipe:
+            pipe.submit(i)  # draw into image i & 1, gather on a second stream; no host wait
+        else:
+            drawer.draw(i & 1)
 
     def fence():
+        if pipe:
+            pipe.finish()
         drawer.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -141,10 +181,11 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    redraws_before = drawer.stats()["redraws"]
     drawer.reset_timing_totals()
-    # events around every kernel cost about 8 % of a frame: sample every fourth frame of the timed
-    # region instead of all of them
-    timing_stride = 4 if args.steps >= 16 else 1
+    # Events around every kernel cost a few per cent of a frame: every fourth frame of the timed
+    # region is sampled, every frame when that would leave fewer than eight samples.
+    timing_stride = 4 if args.steps >= 32 else 1
     drawer.set_timing_stride(timing_stride)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -156,13 +197,25 @@ def main():
     # per-kernel device times: HIP events the library records on its own stream around every
     # kernel of the sampled frames of the timed region
     acc, timed_frames = drawer.timing_totals()
+    stats = drawer.stats()
+    kern = {k: v / max(timed_frames, 1) for k, v in acc.items()}
+    gather_ms = None
+    if pipe:
+        last = args.warmup + args.steps - 1
+        gather_ms = 0.5 * (pipe.last_gather_ms(last) + pipe.last_gather_ms(last - 1)) if args.steps >= 2 else pipe.last_gather_ms(last)
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([kern["object_ms"], kern["setup_ms"], kern["finish_ms"], kern["raster_shade_ms"], kern["frame_ms"],
+                             gather_ms or 0.0, float(stats["records"]), float(stats["bin_entries"]),
+                             float(scissor[1] - scissor[0]) if scissor else float(height)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        names = ["object_ms", "setup_ms", "finish_ms", "raster_shade_ms", "frame_ms", "gather_ms", "records", "bin_entries", "rows"]
+        per_rank = [dict(zip(names, [float(x) for x in r.tolist()])) for r in allr]
 
-    stats = drawer.stats()
-    kern = {k: v / max(timed_frames, 1) for k, v in acc.items()}
     frames_per_step = 1 if (sortfirst or world == 1) else world
     total_frames = frames_per_step * args.steps
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -171,45 +224,55 @@ def main():
 
     result = None
     if rank == 0:
-        cov = drawer.read_depth((args.warmup + args.steps - 1) & 1)
-        covered_px = int((cov < 1.0).sum())
-        tex_bytes = sum(int(t.nbytes) for t in scene.textures)
-        ab = algorithmic_bytes(stats, width, height if not sortfirst else (scissor[1] - scissor[0]), covered_px, tex_bytes)
+        img = (args.warmup + args.steps - 1) & 1
+        rows = (scissor[1] - scissor[0]) if scissor else height
+        depth = drawer.read_depth(img)
+        covered_px = int((depth[scissor[0]:scissor[1]] < 1.0).sum()) if scissor else int((depth < 1.0).sum())
+        ab = algorithmic_bytes(stats, scene, width, rows, covered_px)
         stage_ms = {"setup": kern["setup_ms"], "raster_shade": kern["raster_shade_ms"]}
         dom = max(stage_ms, key=stage_ms.get)
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get(dom)
-            except Exception:
-                traffic = None
+        traffic_all = profile_file("pmc_traffic.json") or {}
+        valu_all = profile_file("pmc_valu_lds.json") or {}
+        valu = next((v for k, v in valu_all.items() if isinstance(v, dict) and ("k_" + dom) in k), {})
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_all.get(dom),
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_ms_per_launch": stage_ms[dom],
+                    # what binds the kernel in practice (tools/pmc_valu_lds.sh, profiles/pmc_valu_lds.json):
+                    # share of the launch during which the vector ALUs of all SIMDs were issuing
+                    "valu_frac": valu.get("valu_busy_frac"), "valu_lane_use": valu.get("valu_lane_use"),
+                    "lds_frac": valu.get("lds_busy_frac")}
+        assert roofline["frac"] <= 1.0, "algorithmic bytes over time exceed the HBM peak: the byte model is wrong"
+        stage = {}
+        for k in stage_ms:
+            g = ab[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0
+            v = next((x for n, x in valu_all.items() if isinstance(x, dict) and ("k_" + k) in n), {})
+            stage[k] = {"algorithmic_bytes": ab[k], "avg_ms": stage_ms[k], "achieved_GBps": g, "hbm_frac": g / HBM_PEAK_GBPS,
+                        "traffic": traffic_all.get(k), "valu_frac": v.get("valu_busy_frac")}
+        stage["setup"]["expanded_buffers_bytes"] = ab["setup_expanded_buffers"]
+        cfg_name = "config %d: %s, %d objects x 1024 triangles = %d triangles, %dx%d, per-frame device-side rotation update" % (
+            args.config, scene.name, len(scene.objects), n_prims, width, height)
         result = {
             "metric": "triangles_per_sec", "value": tri_per_s, "unit": "triangles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if sortfirst else "weak", "vs_baseline": None, "dtype": "f32+i64",
             "data": "synthetic",
             "frames_per_sec": fps,
-            "config": {"workload": "config 3: %s, %d objects x 1024 triangles = %d triangles, %dx%d, "
-                                   "per-frame device-side rotation update" % (scene.name, len(scene.objects), n_prims, width, height),
-                       "parallelism": ("sortfirst-bands%d+rccl-gather" % world) if sortfirst else
+            "config": {"workload": cfg_name,
+                       "parallelism": ("sortfirst-bands%d+rccl-gather-overlapped" % world) if sortfirst else
                                       ("frame-parallel%d" % world if world > 1 else "single"),
                        "frames_per_step": frames_per_step, "tile": stats["tile_size"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom], "avg_ms_per_launch": stage_ms[dom]},
-            # every stage against the same HBM peak, and the whole frame's algorithmic bytes over
-            # the sum of the kernel times (the dominant kernel is the one reported in "roofline")
-            "stage_rooflines": {k: {"algorithmic_bytes": ab[k], "avg_ms": stage_ms[k],
-                                    "achieved_GBps": ab[k] / (stage_ms[k] * 1e-3) / 1e9 if stage_ms[k] > 0 else 0.0}
-                                for k in stage_ms},
-            "frame_roofline": {"algorithmic_bytes": sum(ab.values()), "frame_ms": kern.get("frame_ms", 0.0),
-                               "achieved_GBps": sum(ab.values()) / (kern["frame_ms"] * 1e-3) / 1e9 if kern.get("frame_ms") else 0.0},
+            "roofline": roofline,
+            "stage_rooflines": stage,
             "kernels_ms": kern,
             "kernel_timing": {"frames_sampled": int(timed_frames), "stride": timing_stride},
             "frame_stats": stats,
+            "redraws_in_timed_region": stats["redraws"] - redraws_before,
         }
+        if gather_ms is not None:
+            result["gather_ms"] = gather_ms
+        if per_rank is not None:
+            result["per_rank"] = per_rank
         if args.scale != 1.0:
             result["invalid"] = "scaled-down debug run"
         if world == 1 and not args.no_cpu_baseline:
@@ -219,10 +282,10 @@ def main():
             t = drawer.read_transforms()
             ref = oracle.render(scene, oracle.to_model(t), *oracle.camera(scene.camera, width, height), width, height,
                                 threads=16)
-            img = (args.warmup + args.steps - 1) & 1
-            result["check"] = {"color_equal": bool(np.array_equal(ref["color"], drawer.read_color(img))),
-                               "depth_equal": bool(np.array_equal(ref["depth"].view(np.uint32),
-                                                                  drawer.read_depth(img).view(np.uint32)))}
+            got = pipe.frame.cpu().numpy() if pipe else drawer.read_color(img)
+            y0, y1 = scissor if scissor else (0, height)  # (depth stays on the rank that drew it)
+            result["check"] = {"color_equal": bool(np.array_equal(ref["color"], got)),
+                               "depth_equal": bool(np.array_equal(ref["depth"][y0:y1].view(np.uint32), depth[y0:y1].view(np.uint32)))}
     drawer.close()
     if world > 1:
         dist.barrier()

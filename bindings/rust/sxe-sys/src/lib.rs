@@ -144,6 +144,7 @@ extern "C" {
     pub fn sxe_read_models(ctx: *mut sxe_ctx, models: *mut f32, size_bytes: usize) -> c_int;
     pub fn sxe_read_transforms(ctx: *mut sxe_ctx, transforms: *mut sxe_transform, size_bytes: usize) -> c_int;
     pub fn sxe_color_device_ptr(ctx: *mut sxe_ctx, image_index: u32, ptr: *mut *mut c_void) -> c_int;
+    pub fn sxe_stream(ctx: *mut sxe_ctx, stream: *mut *mut c_void) -> c_int;
     pub fn sxe_get_timings(ctx: *mut sxe_ctx, out: *mut sxe_timings) -> c_int;
     pub fn sxe_get_timing_totals(ctx: *mut sxe_ctx, sums: *mut sxe_timings, frames: *mut u64) -> c_int;
     pub fn sxe_reset_timing_totals(ctx: *mut sxe_ctx) -> c_int;

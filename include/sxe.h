@@ -199,6 +199,10 @@ int sxe_read_models(sxe_ctx *ctx, float *models, size_t size_bytes);
 int sxe_read_transforms(sxe_ctx *ctx, sxe_transform *transforms, size_t size_bytes);
 /* Device address of an image's RGBA8 rows (for a zero-copy RCCL tile gather). */
 int sxe_color_device_ptr(sxe_ctx *ctx, uint32_t image_index, void **ptr);
+/* The context's HIP stream (a hipStream_t), so that a consumer of finished frames can order its own
+ * work after a draw with events instead of a host wait: the counterpart of the present semaphore
+ * that Drawer::draw signals (src/renderer/drawer.rs:437-452). */
+int sxe_stream(sxe_ctx *ctx, void **stream);
 int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
 /* Sums of the per-kernel times over every frame whose result has been taken since the last
  * reset, and the number of those frames: lets a caller keep several frames in flight and still

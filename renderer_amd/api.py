@@ -28,7 +28,7 @@ EXPORTS = [
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
     "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync", "sxe_draw_noalloc",
     "sxe_read_color", "sxe_map_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
-    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
+    "sxe_read_transforms", "sxe_color_device_ptr", "sxe_stream", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
     "sxe_camera_matrices", "sxe_srgb_encode_host",
 ]
@@ -128,6 +128,7 @@ def lib():
                      "sxe_read_tile_times"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.sxe_color_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.sxe_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.sxe_map_color.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8))]
         L.sxe_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
         L.sxe_get_timing_totals.argtypes = [C.c_void_p, C.POINTER(Timings), C.POINTER(C.c_uint64)]
@@ -366,6 +367,12 @@ class HipDrawer:
         p = C.c_void_p()
         self._check(self._L.sxe_color_device_ptr(self._ctx, image_index, C.byref(p)))
         return p.value
+
+    def stream_ptr(self):
+        """The context's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        self._check(self._L.sxe_stream(self._ctx, C.byref(p)))
+        return p.value or 0
 
     def tile_counts(self):
         n = int(self.stats()["tiles"])

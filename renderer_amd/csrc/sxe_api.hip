@@ -1356,6 +1356,14 @@ int sxe_color_device_ptr(sxe_ctx *c, uint32_t image_index, void **ptr)
     return SXE_OK;
 }
 
+int sxe_stream(sxe_ctx *c, void **stream)
+{
+    if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
+    if (!stream) return fail(c, SXE_E_INVALID, "null pointer");
+    *stream = reinterpret_cast<void *>(c->stream);
+    return SXE_OK;
+}
+
 int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
 {
     int rc = check_ctx(c);

@@ -5,7 +5,8 @@ src/renderer/drawer.rs:426-454).  The split follows the two ways its frame decom
 
 * sort-first: the framebuffer is cut into horizontal bands of whole tile rows, one band per rank;
   geometry is replicated, bands are pixel-disjoint, so the only exchange is the final gather of
-  the finished RGBA8 rows (RCCL over xGMI when the backend is "nccl", gloo on CPU);
+  the finished RGBA8 rows (grouped send/receive: RCCL over xGMI when the backend is "nccl", gloo
+  on CPU), overlapped with the drawing of the next frame (SortFirstPipeline);
 * frame-parallel: independent views are dealt to ranks in contiguous blocks; no exchange at all.
 """
 import numpy as np
@@ -37,35 +38,38 @@ def views_for_rank(n_views, world, rank):
     return v0, v0 + base + (1 if rank < extra else 0)
 
 
-def gather_bands(band, height, width, world, rank, dst=0, group=None):
-    """Collect every rank's finished band on rank `dst`.
+def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None):
+    """Collect every rank's finished band on rank `dst`: one send per rank, one receive per sender
+    on `dst`, all posted as one group (on RCCL the receives then run concurrently, one xGMI link
+    per sending GPU), every band at its own size, straight into its rows of the frame.
 
     `band` is this rank's rows as a (rows, width, 4) uint8 torch tensor (a CUDA tensor for the
-    nccl/RCCL backend, a CPU tensor for gloo).  Bands are padded to the tallest band so that one
-    equal-sized gather moves everything; returns the (height, width, 4) frame on `dst`, else None.
+    nccl/RCCL backend, a CPU tensor for gloo).  On `dst` the frame is assembled in `out` (a
+    (height, width, 4) uint8 tensor on the band's device; allocated when None) and returned;
+    other ranks return None.  Ranks whose band is empty take no part in the exchange.
     """
     import torch
     import torch.distributed as dist
 
     bands = all_bands(height, world)
-    max_rows = max(y1 - y0 for y0, y1 in bands)
     y0, y1 = bands[rank]
     if tuple(band.shape) != (y1 - y0, width, 4) or band.dtype != torch.uint8:
         raise ValueError("band has shape %s, expected %s uint8" % (tuple(band.shape), (y1 - y0, width, 4)))
-    send = band
-    if y1 - y0 != max_rows:
-        send = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=band.device)
-        send[: y1 - y0] = band
-    send = send.contiguous()
-    if world == 1:
-        return send[: y1 - y0]
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
+    band = band.contiguous()
     if rank != dst:
+        if y1 > y0 and world > 1:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, band, dst, group)]):
+                w.wait()
         return None
-    frame = torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
-    for r, (a, b) in enumerate(bands):
-        frame[a:b] = recv[r][: b - a]
+    frame = out if out is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
+    if tuple(frame.shape) != (height, width, 4) or frame.dtype != torch.uint8 or not frame.is_contiguous():
+        raise ValueError("out must be a contiguous (%d, %d, 4) uint8 tensor" % (height, width))
+    ops = [dist.P2POp(dist.irecv, frame[a:b], r, group) for r, (a, b) in enumerate(bands) if r != dst and b > a]
+    if y1 > y0:
+        frame[y0:y1].copy_(band)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return frame
 
 
@@ -91,6 +95,57 @@ def frame_hash(color):
     a = np.ascontiguousarray(color).view(np.uint8).ravel().astype(np.uint64)
     idx = np.arange(1, a.size + 1, dtype=np.uint64)
     return int(((a + np.uint64(1)) * (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))).sum(dtype=np.uint64))
+
+
+class SortFirstPipeline:
+    """Sort-first rendering of a frame sequence on one rank: this rank's band of frame i is drawn
+    into image i % 2 on the drawer's own stream while the band of frame i - 1 is being gathered on
+    a second stream, ordered by events only (the host never waits inside the loop).
+
+    The drawer must have been created with this rank's scissor band and at least two images.
+    Frames that overflow a work buffer are drawn again by the library when it takes their result,
+    which is after their band was sent: call `drawer.sync()` and check `stats()["redraws"]` when
+    that matters (it cannot happen once the buffers have grown to the scene).
+    """
+
+    def __init__(self, drawer, height, width, world, rank, dst=0, group=None):
+        import torch
+        self.d, self.h, self.w, self.world, self.rank, self.dst, self.group = drawer, height, width, world, rank, dst, group
+        self.y0, self.y1 = band_rows(height, world, rank)
+        dev = torch.device("cuda", drawer.cfg.device)
+        self.lib_stream = torch.cuda.ExternalStream(drawer.stream_ptr(), device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.drawn = [torch.cuda.Event() for _ in range(2)]
+        self.gathered = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.gather_start = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.used = [False, False]
+        self.frame = torch.empty((height, width, 4), dtype=torch.uint8, device=dev) if rank == dst else None
+        self.bands = [band_tensor(drawer, img, self.y0, self.y1) for img in range(2)]
+
+    def submit(self, i):
+        """Draw frame i (the caller has set uniforms and camera) and start gathering it."""
+        import torch
+        img = i & 1
+        if self.used[img]:
+            self.lib_stream.wait_event(self.gathered[img])  # the band of frame i - 2 has left this image
+        self.d.draw(img)
+        self.drawn[img].record(self.lib_stream)
+        self.side.wait_event(self.drawn[img])
+        with torch.cuda.stream(self.side):
+            self.gather_start[img].record(self.side)
+            gather_bands(self.bands[img], self.h, self.w, self.world, self.rank, self.dst, self.group, out=self.frame)
+            self.gathered[img].record(self.side)
+        self.used[img] = True
+
+    def finish(self):
+        """Wait for everything submitted; returns the last frame on `dst` (else None)."""
+        self.d.sync()
+        self.side.synchronize()
+        return self.frame
+
+    def last_gather_ms(self, i):
+        """Device time of frame i's gather on this rank (after finish())."""
+        return self.gather_start[i & 1].elapsed_time(self.gathered[i & 1])
 
 
 class ViewPool:

@@ -1,5 +1,5 @@
 """Multi-rank host logic on CPU: band partition, view split and the band gather over gloo with
-two processes.  The renderer in these processes is the CPU oracle (test infrastructure) standing
+two and three processes.  The renderer in these processes is the CPU oracle (test infrastructure) standing
 in for the GPU, because the point here is the split/gather code, not the kernels."""
 import os
 import socket
@@ -51,28 +51,36 @@ def _worker(rank, world, port, out_path):
     models = oracle.to_model(s.transforms)
     view, proj = oracle.camera(s.camera, w, h)
     y0, y1 = sh.band_rows(h, world, rank)
+    heights = [b - a for a, b in sh.all_bands(h, world)]
+    if world == 3:
+        assert len(set(heights)) > 1, "this case is meant to have bands of different heights"
     band = oracle.render(s, models, view, proj, w, h, scissor=(y0, y1))["color"][y0:y1]
     frame = sh.gather_bands(torch.from_numpy(np.ascontiguousarray(band)), h, w, world, rank)
+    # a second frame into a caller-provided buffer, as the overlapped pipeline does it
+    out = torch.full((h, w, 4), 7, dtype=torch.uint8) if rank == 0 else None
+    again = sh.gather_bands(torch.from_numpy(np.ascontiguousarray(band)), h, w, world, rank, out=out)
     # frame-parallel bookkeeping: max-over-ranks timing as bench.py does it
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == world
     if rank == 0:
         full = oracle.render(s, models, view, proj, w, h)["color"]
-        ok = frame is not None and np.array_equal(frame.numpy(), full)
+        ok = frame is not None and np.array_equal(frame.numpy(), full) and again is out and np.array_equal(out.numpy(), full)
         with open(out_path, "w") as f:
             f.write("ok" if ok else "mismatch")
     else:
-        assert frame is None
+        assert frame is None and again is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sort_first_gather_two_ranks_gloo(tmp_path, orc):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sort_first_gather_gloo(tmp_path, orc, world):
+    """Bands of equal (two ranks) and of different heights (three ranks), sent at their own sizes."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert open(out).read() == "ok"

@@ -10,7 +10,7 @@ import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
 
-NAMES = {"k_setup": "setup", "k_raster_shade": "raster_shade", "k_bin": "bin", "k_scan": "scan", "k_object": "object",
+NAMES = {"k_setup": "setup", "k_raster_shade": "raster_shade", "k_finish": "finish", "k_object": "object",
          "k_clip": "clip", "k_rotation_system": "transform"}
 
 def main():

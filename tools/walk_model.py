@@ -51,7 +51,7 @@ def iterations(key):
     return np.maximum.reduceat(b, np.flatnonzero(np.r_[1, np.diff(wave)])).sum()
 
 
-for bounds in ([2, 8, 24], [1, 2, 4, 8, 12, 24], [1, 2, 3, 4, 6, 8, 12, 16, 24], [1, 2, 4, 6, 9, 12, 16, 24]):
+for bounds in ([2, 8, 24], [2, 4, 8, 24], [2, 4, 8, 14, 24], [2, 4, 6, 9, 14, 24], [1, 2, 4, 8, 12, 24], [2, 4, 6, 8, 12, 16, 24], [1, 2, 3, 4, 6, 8, 12, 16, 24]):
     cls = np.searchsorted(np.array(bounds), sz)
     print("classes <= %s: %d wave iterations" % (bounds, iterations(cls)))
 print("sorted by box size: %d wave iterations" % iterations(sz))
