@@ -134,6 +134,7 @@ extern "C" {
     pub fn sxe_update_camera_matrices(ctx: *mut sxe_ctx, view: *const f32, proj: *const f32) -> c_int;
     pub fn sxe_draw(ctx: *mut sxe_ctx, image_index: u32) -> c_int;
     pub fn sxe_sync(ctx: *mut sxe_ctx) -> c_int;
+    pub fn sxe_draw_views(ctx: *mut sxe_ctx, cameras: *const sxe_transform, n: u32, first_image: u32) -> c_int;
     /// draw + sync with every work buffer in the library's static device array (allocates nothing).
     pub fn sxe_draw_noalloc(ctx: *mut sxe_ctx, image_index: u32) -> c_int;
     pub fn sxe_read_color(ctx: *mut sxe_ctx, image_index: u32, rgba: *mut u8, size_bytes: usize) -> c_int;

@@ -166,6 +166,14 @@ int sxe_update_camera_matrices(sxe_ctx *ctx, const float *view, const float *pro
 /* Drawer::draw (src/renderer/drawer.rs:412-456): enqueue one frame into image `image_index`;
  * asynchronous on the context's stream. */
 int sxe_draw(sxe_ctx *ctx, uint32_t image_index);
+/* update_camera + draw (src/renderer/drawer.rs:507-518, :412-456) for n independent views of the
+ * resident scene in one go: view v is seen by cameras[v] and rendered into image first_image + v
+ * (the context needs that many images).  The views of a set share every kernel launch (the view is
+ * one more grid dimension), which is what makes thousands of small views cheap: one at a time they
+ * cost a launch chain each.  Every view comes out exactly as sxe_update_camera + sxe_draw would
+ * render it.  The library cuts n into sets that fit its work buffers (up to 64 views) and enqueues
+ * them like frames of sxe_draw; a pending rotation-system update is applied first, once. */
+int sxe_draw_views(sxe_ctx *ctx, const sxe_transform *cameras, uint32_t n, uint32_t first_image);
 /* The fence wait of src/renderer/drawer.rs:416-424.  Reports deferred device-side failures. */
 int sxe_sync(sxe_ctx *ctx);
 /* sxe_draw + sxe_sync for callers that cannot allocate (code under HIP graph capture, tight serving

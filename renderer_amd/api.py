@@ -26,7 +26,7 @@ E_INVALID, E_DEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4
 EXPORTS = [
     "sxe_default_config", "sxe_create", "sxe_destroy", "sxe_last_error", "sxe_version", "sxe_set_textures",
     "sxe_update_drawables", "sxe_update_instances", "sxe_update_uniforms", "sxe_update_transforms",
-    "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_sync", "sxe_draw_noalloc",
+    "sxe_rotation_system", "sxe_rotation_system_span", "sxe_update_camera", "sxe_update_camera_matrices", "sxe_draw", "sxe_draw_views", "sxe_sync", "sxe_draw_noalloc",
     "sxe_read_color", "sxe_map_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
     "sxe_read_transforms", "sxe_color_device_ptr", "sxe_stream", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
@@ -121,6 +121,7 @@ def lib():
         L.sxe_update_camera_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sxe_draw.argtypes = [C.c_void_p, C.c_uint32]
         L.sxe_sync.argtypes = [C.c_void_p]
+        L.sxe_draw_views.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.sxe_draw_noalloc.argtypes = [C.c_void_p, C.c_uint32]
         for name in ("sxe_read_color", "sxe_read_depth", "sxe_read_coverage"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
@@ -324,6 +325,12 @@ class HipDrawer:
 
     def draw(self, image_index=0):
         self._check(self._L.sxe_draw(self._ctx, image_index))
+
+    def draw_views(self, cameras, first_image=0):
+        """One view per camera Transform into images first_image, first_image + 1, ...; the views
+        share their kernel launches."""
+        cams = np.ascontiguousarray(cameras, dtype=TRANSFORM)
+        self._check(self._L.sxe_draw_views(self._ctx, _p(cams), len(cams), first_image))
 
     def sync(self):
         self._check(self._L.sxe_sync(self._ctx))

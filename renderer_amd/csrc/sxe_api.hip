@@ -50,10 +50,12 @@ struct DevBuf {
     }
 };
 
+// The images of a context lie one behind the other in one allocation per plane, so that a set of
+// views can render into consecutive images with one launch.
 struct Image {
-    DevBuf<uint8_t> color;
-    DevBuf<float> depth;
-    DevBuf<uint32_t> prim;
+    uint8_t *color = nullptr;
+    float *depth = nullptr;
+    uint32_t *prim = nullptr;   // null unless the context keeps coverage
     uint8_t *h_color = nullptr; // pinned copy handed out by sxe_map_color (allocated on first use)
     bool drawn = false;
 };
@@ -76,7 +78,9 @@ struct FrameSlot {
     hipEvent_t done = nullptr;
     bool pending = false, transform_timed = false;
     bool timed = false; // this frame's kernels are bracketed by events
-    uint32_t image = 0;
+    uint32_t image = 0; // first image of the launch set
+    uint32_t views = 1; // views in the launch set: they render into images image .. image + views - 1
+    DevBuf<float> pv_views; // proj * view of every view of a set of several
 };
 
 // The device memory one frame works in besides its inputs and its images: per-object matrices,
@@ -168,6 +172,10 @@ struct sxe_ctx {
     BinLayout bl = {};       // capacities of the five bin regions every tile has; the bin array holds n_tiles * bl.stride entries
 
     std::vector<Image> images;
+    DevBuf<uint8_t> color_pool;
+    DevBuf<float> depth_pool;
+    DevBuf<uint32_t> prim_pool;
+    uint32_t view_capacity = 1; // views per launch set the work buffers are sized for
     FrameSlot slots[kFrameSlots];
     uint64_t frames_enqueued = 0, frames_retired = 0; // frame f lives in slot f % kFrameSlots
     sxe_timings timings = {};
@@ -246,6 +254,7 @@ FrameGeom make_geom(const sxe_config &cfg)
     g.n_tiles = g.tiles_x * g.n_tile_rows;
     g.half_w = (float)cfg.width * 0.5f;
     g.half_h = (float)cfg.height * 0.5f;
+    g.views = 1;
     return g;
 }
 
@@ -266,7 +275,7 @@ struct HostObject {
 // Record arrays: 256 slots per setup work item, then fan_capacity slots for clipped fans.
 hipError_t reserve_records(sxe_ctx *c)
 {
-    const size_t n = (size_t)c->n_blocks * kSetupThreads + c->fan_capacity;
+    const size_t n = (size_t)c->view_capacity * c->n_blocks * kSetupThreads + c->fan_capacity;
     hipError_t e;
     if ((e = c->rast.reserve(n)) != hipSuccess) return e;
     if ((e = c->wide.reserve(n)) != hipSuccess) return e;
@@ -298,10 +307,11 @@ int set_bin_layout(sxe_ctx *c, const uint32_t want[kBinRegions])
         cap[r] = std::max(want[r], c->bl.cap[r]);
         stride += ((uint64_t)cap[r] + 63u) & ~(uint64_t)63u;
     }
-    const uint64_t total = stride * std::max<uint32_t>(c->g.n_tiles, 1);
+    const uint64_t tiles = (uint64_t)std::max<uint32_t>(c->g.n_tiles, 1) * c->view_capacity;
+    const uint64_t total = stride * tiles;
     if (total > 0xFFFFFFF0ull)
-        return fail(c, SXE_E_CAPACITY, "bins of %llu entries per tile for %u tiles exceed 2^32 entries", (unsigned long long)stride,
-                    c->g.n_tiles);
+        return fail(c, SXE_E_CAPACITY, "bins of %llu entries per tile for %llu tiles exceed 2^32 entries", (unsigned long long)stride,
+                    (unsigned long long)tiles);
     layout_from_caps(c->bl, cap);
     SXE_HIP(c, c->bins.reserve((size_t)total));
     return SXE_OK;
@@ -446,11 +456,12 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     std::vector<uint32_t> object_mesh(ho.size());
     for (size_t o = 0; o < ho.size(); ++o) object_mesh[o] = ho[o].mesh;
     SXE_HIP(c, up(c->object_mesh, object_mesh));
+    if ((uint64_t)blocks.size() * kSetupThreads * c->view_capacity > 0x7FFFFFFFull) c->view_capacity = 1; // (slots are 32-bit)
     for (FrameSlot &fs : c->slots) {
-        SXE_HIP(c, fs.visible.reserve(std::max<size_t>(ho.size(), 1)));
-        SXE_HIP(c, fs.pvm.reserve(std::max<size_t>(models.size(), 16)));
+        SXE_HIP(c, fs.visible.reserve(std::max<size_t>(ho.size(), 1) * c->view_capacity));
+        SXE_HIP(c, fs.pvm.reserve(std::max<size_t>(models.size(), 16) * c->view_capacity));
     }
-    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1)));
+    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1) * c->view_capacity));
 
     c->n_meshes = (uint32_t)hm.size();
     c->n_objects = (uint32_t)ho.size();
@@ -576,12 +587,16 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     Image &img = c->images[fs.image];
     const bool timing = fs.timed;
     hipStream_t s = c->stream;
-    const uint32_t nt = c->g.n_tiles;
+    FrameGeom g = c->g;
+    g.views = fs.views;
+    const uint32_t nt = total_tiles(g); // of all views of the set
 
     const size_t ntc = std::max<uint32_t>(nt, 1);
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BEGIN], s));
     {
         ObjectArgs oa = object_args(c, w);
+        oa.g = g;
+        oa.pv_views = fs.views > 1 ? fs.pv_views.p : nullptr;
         oa.objects = fresh ? 1u : 0u;
         if (fresh && c->rot_pending) {
             oa.rot_seed = c->rot_seed;
@@ -603,10 +618,11 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.blocks = c->blocks.p;
     sa.pvm = w.pvm;
     sa.visible = w.visible;
+    sa.n_objects = c->n_objects;
     sa.n_blocks = c->n_blocks;
     sa.shading = c->cfg.shading;
     sa.debug = c->cfg.flags & kDebugMask;
-    sa.g = c->g;
+    sa.g = g;
     sa.blk_count = w.blk_count;
     sa.tiles = reinterpret_cast<TileCtr *>(w.tile_counters);
     sa.bins = w.bins;
@@ -626,13 +642,14 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_SETUP], s));
 
     FinishArgs fa{};
-    fa.g = c->g;
+    fa.g = g;
     fa.blk_count = w.blk_count;
     fa.n_blocks = c->n_blocks;
     fa.walk_blocks = 128; // 1024 waves share the list of late entries, however long it is
     fa.rast = w.rast;
     fa.wide = w.wide;
     fa.walk_list = w.walk_list;
+    fa.fan_order = w.fan_order;
     fa.tiles = sa.tiles;
     fa.late_fill = w.tile_counters + 8 * ntc;
     fa.tile_launch = w.tile_launch;
@@ -643,7 +660,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_FINISH], s));
 
     RasterArgs ra{};
-    ra.g = c->g;
+    ra.g = g;
     ra.tile_launch = w.tile_launch;
     ra.bins = w.bins;
     ra.bl = w.bl;
@@ -652,14 +669,15 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     ra.shade = w.shade;
     ra.color = w.color;
     ra.fan_order = w.fan_order;
-    ra.n_slots = c->n_blocks * kSetupThreads;
+    ra.n_slots = fs.views * c->n_blocks * kSetupThreads;
+    ra.image_stride = (size_t)c->cfg.width * c->cfg.height;
     ra.counters = w.counters;
     ra.texels = c->texels.p;
     ra.textures = c->textab.p;
     ra.n_textures = c->n_textures;
-    ra.out_color = img.color.p;
-    ra.out_depth = img.depth.p;
-    ra.out_prim = (c->cfg.flags & SXE_FLAG_WRITE_COVERAGE) ? img.prim.p : nullptr;
+    ra.out_color = img.color;
+    ra.out_depth = img.depth;
+    ra.out_prim = (c->cfg.flags & SXE_FLAG_WRITE_COVERAGE) ? img.prim : nullptr;
     ra.clear_code = srgb_encode_host(c->cfg.clear[0]) | (srgb_encode_host(c->cfg.clear[1]) << 8) |
                     (srgb_encode_host(c->cfg.clear[2]) << 16) | (unorm8_host(c->cfg.clear[3]) << 24);
     ra.shading = c->cfg.shading;
@@ -674,7 +692,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
 
     if (!direct) SXE_HIP(c, hipMemcpyAsync(fs.h_counters, w.counters, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
     SXE_HIP(c, hipEventRecord(fs.done, s));
-    img.drawn = true;
+    for (uint32_t v = 0; v < fs.views; ++v) c->images[fs.image + v].drawn = true;
     fs.pending = true;
     return SXE_OK;
 }
@@ -754,6 +772,40 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     w.fan_capacity = kNoAllocFan;
     w.with_clip = true; // always: a frame that finds a triangle to clip cannot be drawn again here
     return true;
+}
+
+// How many of `n` views go into one launch set: as many as keep the set's work buffers around
+// 1 GiB (records of 100 bytes per slot, bins), at most 64, and within 32-bit slot numbers.
+uint32_t views_per_set(const sxe_ctx *c, uint32_t n)
+{
+    const uint64_t slots = std::max<uint64_t>((uint64_t)c->n_blocks * kSetupThreads, 1);
+    const uint64_t per_view = slots * 100 + (uint64_t)std::max<uint32_t>(c->g.n_tiles, 1) * (4ull * std::max<uint32_t>(c->bl.stride, 64) + 72) +
+                              (uint64_t)c->n_objects * 65;
+    uint64_t k = std::max<uint64_t>((1ull << 30) / per_view, 1);
+    k = std::min<uint64_t>(k, 0x7FFFFFFFull / slots);
+    k = std::min<uint64_t>(std::min<uint64_t>(k, 64), n);
+    return (uint32_t)std::max<uint64_t>(k, 1);
+}
+
+// Sizes every per-frame buffer for launch sets of `views` views.  Nothing may be lost: frames in
+// flight are taken out first.
+int ensure_views(sxe_ctx *c, uint32_t views)
+{
+    if (views <= c->view_capacity) return SXE_OK;
+    int rc = sxe_sync(c);
+    if (rc) return rc;
+    c->view_capacity = views;
+    const size_t nt = (size_t)std::max<uint32_t>(c->g.n_tiles, 1) * views;
+    for (FrameSlot &fs : c->slots) {
+        SXE_HIP(c, fs.visible.reserve(std::max<size_t>(c->n_objects, 1) * views));
+        SXE_HIP(c, fs.pvm.reserve(std::max<size_t>((size_t)c->n_objects * 16, 16) * views));
+        SXE_HIP(c, fs.pv_views.reserve(16 * (size_t)views));
+    }
+    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(c->n_blocks, 1) * views));
+    SXE_HIP(c, c->tile_counters.reserve(9 * nt));
+    SXE_HIP(c, c->tile_launch.reserve(nt));
+    SXE_HIP(c, reserve_records(c));
+    return set_bin_layout(c, c->bl.cap);
 }
 
 // Takes the result of the oldest frame in flight: waits for it, and if one of its work buffers
@@ -845,7 +897,7 @@ int read_image_plane(sxe_ctx *c, uint32_t image_index, void *dst, size_t size_by
     if (!dst || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     rc = sxe_sync(c);
     if (rc) return rc;
-    const void *src = plane == 0 ? (const void *)img.color.p : plane == 1 ? (const void *)img.depth.p : (const void *)img.prim.p;
+    const void *src = plane == 0 ? (const void *)img.color : plane == 1 ? (const void *)img.depth : (const void *)img.prim;
     if (!src) return fail(c, SXE_E_STATE, "coverage was not requested (SXE_FLAG_WRITE_COVERAGE)");
     // rows outside the scissor were never written: report them as cleared
     SXE_HIP(c, hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
@@ -901,7 +953,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if (k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask))
         return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask));
     if (k.n_images == 0) k.n_images = 1;
-    if (k.n_images > 16) return fail(nullptr, SXE_E_CAPACITY, "at most 16 images");
+    if (k.n_images > 65536) return fail(nullptr, SXE_E_CAPACITY, "at most 65536 images");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -948,18 +1000,21 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     }
     const size_t px = (size_t)k.width * k.height;
     c->images.resize(k.n_images);
-    for (auto &img : c->images) {
-        if ((e = img.color.reserve(px * 4)) != hipSuccess) return bail("hipMalloc(color)", e);
-        if ((e = img.depth.reserve(px)) != hipSuccess) return bail("hipMalloc(depth)", e);
-        if (k.flags & SXE_FLAG_WRITE_COVERAGE)
-            if ((e = img.prim.reserve(px)) != hipSuccess) return bail("hipMalloc(coverage)", e);
-        // rows outside the scissor are never written by a frame: start them cleared
-        if ((e = hipMemset(img.color.p, 0, px * 4)) != hipSuccess) return bail("hipMemset", e);
-        if ((e = hipMemset(img.depth.p, 0, px * 4)) != hipSuccess) return bail("hipMemset", e);
-        if (img.prim.p && (e = hipMemset(img.prim.p, 0xFF, px * 4)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = c->color_pool.reserve(px * 4 * k.n_images)) != hipSuccess) return bail("hipMalloc(color)", e);
+    if ((e = c->depth_pool.reserve(px * k.n_images)) != hipSuccess) return bail("hipMalloc(depth)", e);
+    if (k.flags & SXE_FLAG_WRITE_COVERAGE)
+        if ((e = c->prim_pool.reserve(px * k.n_images)) != hipSuccess) return bail("hipMalloc(coverage)", e);
+    // rows outside the scissor are never written by a frame: start them cleared
+    if ((e = hipMemset(c->color_pool.p, 0, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(c->depth_pool.p, 0, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
+    if (c->prim_pool.p && (e = hipMemset(c->prim_pool.p, 0xFF, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
+    for (uint32_t i = 0; i < k.n_images; ++i) {
+        c->images[i].color = c->color_pool.p + px * 4 * i;
+        c->images[i].depth = c->depth_pool.p + px * i;
+        c->images[i].prim = c->prim_pool.p ? c->prim_pool.p + px * i : nullptr;
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(10 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_counters.reserve(9 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_launch.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile launch records)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
@@ -980,8 +1035,8 @@ void sxe_destroy(sxe_ctx *c)
     c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->walk_list.release(); c->fan_order.release(); c->tile_launch.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
+    c->color_pool.release(); c->depth_pool.release(); c->prim_pool.release();
     for (auto &img : c->images) {
-        img.color.release(); img.depth.release(); img.prim.release();
         if (img.h_color) (void)hipHostFree(img.h_color);
     }
     for (auto &st : c->staging) {
@@ -989,7 +1044,7 @@ void sxe_destroy(sxe_ctx *c)
         if (st.done) (void)hipEventDestroy(st.done);
     }
     for (FrameSlot &fs : c->slots) {
-        fs.pvm.release(); fs.visible.release();
+        fs.pvm.release(); fs.visible.release(); fs.pv_views.release();
         if (fs.h_counters) (void)hipHostFree(fs.h_counters);
         for (int i = 0; i < EV_N; ++i) if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
         for (int i = 0; i < 2; ++i) if (fs.ev_tr[i]) (void)hipEventDestroy(fs.ev_tr[i]);
@@ -1174,10 +1229,64 @@ int sxe_draw(sxe_ctx *c, uint32_t image_index)
     }
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
     fs.image = image_index;
+    fs.views = 1;
     fs.timed = frame_is_timed(c, c->frames_enqueued);
     rc = enqueue_frame(c, fs, true, context_bufs(c, fs));
     if (rc) return rc;
     c->frames_enqueued++;
+    return SXE_OK;
+}
+
+int sxe_draw_views(sxe_ctx *c, const sxe_transform *cameras, uint32_t n, uint32_t first_image)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(c, SXE_E_STATE, "draw before update_drawables");
+    if (n && !cameras) return fail(c, SXE_E_INVALID, "null camera array");
+    if ((uint64_t)first_image + n > c->images.size())
+        return fail(c, SXE_E_INVALID, "views %u..%u do not fit the context's %zu images", first_image, first_image + n, c->images.size());
+    if (n == 0) return SXE_OK;
+    rc = flush_rotation(c); // the first kernel of a set of several views does not carry the update
+    if (rc) return rc;
+    const uint32_t per_set = views_per_set(c, n);
+    rc = ensure_views(c, per_set);
+    if (rc) return rc;
+    const float aspect = (float)c->cfg.width / (float)c->cfg.height;
+    std::vector<float> pv(16 * (size_t)per_set);
+    for (uint32_t v0 = 0; v0 < n; v0 += per_set) {
+        const uint32_t nv = std::min(per_set, n - v0);
+        if (c->frames_enqueued - c->frames_retired >= (uint64_t)kFrameSlots) {
+            rc = retire_oldest(c);
+            if (rc) return rc;
+        }
+        FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
+        // update_camera (src/renderer/drawer.rs:507-518) for every view of the set
+        for (uint32_t v = 0; v < nv; ++v) {
+            float view[16], proj[16];
+            sxe_camera_matrices(&cameras[v0 + v], c->cfg.fov_deg, aspect, c->cfg.z_near, c->cfg.z_far, view, proj);
+            Mat4 V, P;
+            memcpy(V.m, view, 64);
+            memcpy(P.m, proj, 64);
+            const Mat4 PV = mul(P, V);
+            memcpy(&pv[16 * (size_t)v], PV.m, 64);
+            if (v0 + v + 1 == n) { // the context's camera ends up as the last view's, as after n calls of update_camera
+                c->view = V;
+                c->proj = P;
+                c->pv = PV;
+                c->have_camera = true;
+            }
+        }
+        SXE_HIP(c, fs.pv_views.reserve(16 * (size_t)c->view_capacity));
+        rc = stage_upload(c, fs.pv_views.p, pv.data(), 64 * (size_t)nv);
+        if (rc) return rc;
+        fs.image = first_image + v0;
+        fs.views = nv;
+        fs.timed = frame_is_timed(c, c->frames_enqueued);
+        if (nv == 1) c->pv = *reinterpret_cast<const Mat4 *>(&pv[0]); // (a set of one goes the single-view way)
+        rc = enqueue_frame(c, fs, true, context_bufs(c, fs));
+        if (rc) return rc;
+        c->frames_enqueued++;
+    }
     return SXE_OK;
 }
 
@@ -1220,6 +1329,7 @@ int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
     // counters and per-tile tables, and every other table entry is written before it is read.
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];
     fs.image = image_index;
+    fs.views = 1;
     fs.timed = false;
     rc = enqueue_frame(c, fs, true, w);
     if (rc) return rc;
@@ -1283,7 +1393,7 @@ int sxe_map_color(sxe_ctx *c, uint32_t image_index, const uint8_t **rgba)
     if (!img.h_color) SXE_HIP(c, hipHostMalloc(reinterpret_cast<void **>(&img.h_color), need, hipHostMallocDefault));
     rc = sxe_sync(c);
     if (rc) return rc;
-    SXE_HIP(c, hipMemcpyAsync(img.h_color, img.color.p, need, hipMemcpyDeviceToHost, c->stream));
+    SXE_HIP(c, hipMemcpyAsync(img.h_color, img.color, need, hipMemcpyDeviceToHost, c->stream));
     SXE_HIP(c, hipStreamSynchronize(c->stream));
     *rgba = img.h_color;
     return SXE_OK;
@@ -1352,7 +1462,7 @@ int sxe_color_device_ptr(sxe_ctx *c, uint32_t image_index, void **ptr)
 {
     if (!c) return fail(nullptr, SXE_E_INVALID, "null context");
     if (!ptr || image_index >= c->images.size()) return fail(c, SXE_E_INVALID, "bad image index or null pointer");
-    *ptr = c->images[image_index].color.p;
+    *ptr = c->images[image_index].color;
     return SXE_OK;
 }
 

@@ -60,15 +60,26 @@ __device__ inline Mat4 rotate_object(sxe_transform *t, float *models, uint32_t i
 // for objects that project wholly above or below the scissor rows.  Skipping such objects changes
 // no pixel.
 // It is also the first kernel of a frame and clears the frame's counters on the way.
+// Grid: x over the objects, y over the views of the launch set.
 __global__ void k_object(ObjectArgs a)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t z = i; z < a.n_zero; z += gridDim.x * blockDim.x) a.zero[z] = 0u;
-    if (i < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t *>(a.counters)[i] = 0u;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, view = blockIdx.y;
+    const uint32_t lin = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    for (uint32_t z = lin; z < a.n_zero; z += gridDim.x * gridDim.y * blockDim.x) a.zero[z] = 0u;
+    if (lin < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t *>(a.counters)[lin] = 0u;
     if (i >= a.n || !a.objects) return;
+    Mat4 PV = a.pv;
+    if (a.pv_views) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.pv_views + 16 * (size_t)view);
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = src[c];
+            PV.m[4 * c] = v.x; PV.m[4 * c + 1] = v.y; PV.m[4 * c + 2] = v.z; PV.m[4 * c + 3] = v.w;
+        }
+    }
     Mat4 M;
     if (a.rot_n) {
         // the rotation system's update of this frame rides along: one launch less per frame
+        // (single view only: the host launches it on its own before a set of several views)
         M = rotate_object(a.transforms, a.models_rw, i, a.rot_seed, a.rot_first, a.rot_n, a.rot_delta_ms);
     } else {
         const float4 *src = reinterpret_cast<const float4 *>(a.models + 16 * (size_t)i);
@@ -77,8 +88,9 @@ __global__ void k_object(ObjectArgs a)
             M.m[4 * c] = v.x; M.m[4 * c + 1] = v.y; M.m[4 * c + 2] = v.z; M.m[4 * c + 3] = v.w;
         }
     }
-    const Mat4 R = mul(a.pv, M);
-    float4 *dst = reinterpret_cast<float4 *>(a.pvm + 16 * (size_t)i);
+    const Mat4 R = mul(PV, M);
+    const size_t vi = (size_t)view * a.n + i;
+    float4 *dst = reinterpret_cast<float4 *>(a.pvm + 16 * vi);
     for (int c = 0; c < 4; ++c) dst[c] = make_float4(R.m[4 * c], R.m[4 * c + 1], R.m[4 * c + 2], R.m[4 * c + 3]);
 
     const MeshDev mesh = a.meshes[a.object_mesh[i]];
@@ -112,7 +124,7 @@ __global__ void k_object(ObjectArgs a)
     // scissor rows: only when every corner is in front of the eye (then the projection is bounded)
     if (w_pos && (ys_max < (float)a.g.sy0 - 2.0f || ys_min > (float)a.g.sy1 + 2.0f)) vis = false;
     if (mesh.n_tri == 0) vis = false;
-    a.visible[i] = vis ? 1 : 0;
+    a.visible[vi] = vis ? 1 : 0;
 }
 
 // Transform::to_ubo for every object (src/components/transform.rs:69-80, loop at src/main.rs:237-244).
@@ -361,12 +373,13 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, const Scr
 }
 
 // One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
-__device__ inline void count_box(const SetupArgs &a, const ScreenTri &s)
+__device__ inline void count_box(const SetupArgs &a, uint32_t view, const ScreenTri &s)
 {
     const int32_t tx0 = s.px0 / kTile, tx1 = s.px1 / kTile;
     const int32_t ty0 = s.py0 / kTile - (int32_t)a.g.tile_row0, ty1 = s.py1 / kTile - (int32_t)a.g.tile_row0;
+    TileCtr *tiles = a.tiles + (size_t)view * a.g.n_tiles;
     for (int32_t ty = ty0; ty <= ty1; ++ty)
-        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&a.tiles[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx].multi, 1u);
+        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&tiles[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx].multi, 1u);
 }
 
 // One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object
@@ -388,7 +401,7 @@ struct SetupShared {
     };
 };
 
-__device__ inline void setup_block(const SetupArgs &a, const uint32_t block, SetupShared &sh)
+__device__ inline void setup_block(const SetupArgs &a, const uint32_t block, const uint32_t view, SetupShared &sh)
 {
     uint32_t *s_wave_tot = sh.wave_tot;
     int2 *s_xy = sh.vtx.xy;
@@ -401,11 +414,13 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // Triangles that are neighbours in the index list share most of their vertices: when the
     // vertex range of these 256 triangles fits the cache, every vertex is projected once.
     const bool cached = bd.vtx_n <= (uint32_t)kVtxCache;
-    if (!a.visible[bd.object]) {
-        if (tid == 0) a.blk_count[block] = 0;
+    const uint32_t vblock = view * a.n_blocks + block; // work item number over all views: names its record slots
+    const size_t vobject = (size_t)view * a.n_objects + bd.object;
+    if (!a.visible[vobject]) {
+        if (tid == 0) a.blk_count[vblock] = 0;
         return;
     }
-    const float *pvm = a.pvm + 16 * (size_t)bd.object;
+    const float *pvm = a.pvm + 16 * vobject;
     if (cached) {
         for (uint32_t i = (uint32_t)tid; i < bd.vtx_n; i += kSetupThreads) {
             const sxe_vertex &w = a.vertices[bd.vtx_base + bd.vtx_lo + i];
@@ -418,7 +433,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         __syncthreads();
     }
     if ((a.debug & kDebugSkipRaster) && (a.debug & kDebugSkipResolve)) { // development: stop after the vertex phase
-        if (tid == 0) a.blk_count[block] = 0;
+        if (tid == 0) a.blk_count[vblock] = 0;
         return;
     }
 
@@ -478,9 +493,10 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         if (w < wave) wave_base += v;
         total += v;
     }
-    if (tid == 0) a.blk_count[block] = total;
+    if (tid == 0) a.blk_count[vblock] = total;
     const uint32_t local = wave_base + wave_rank;
-    const uint32_t slot0 = block * kSetupThreads, slot = slot0 + local;
+    const uint32_t slot0 = vblock * kSetupThreads, slot = slot0 + local;
+    const uint32_t tile0 = view * a.g.n_tiles; // the view's first tile in the per-tile tables and the bins
     const uint32_t prim = bd.prim_base + t;
 
     // Bin entries of triangles that lie in one tile are reserved here, one atomic per (tile, size
@@ -500,7 +516,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     uint32_t raw4[4] = {0, 0, 0, 0};   // the group's reservation, valid in its leader lane
     uint32_t who4[4] = {0, 0, 0, 0};   // leader lane | rank inside the group << 8
     {
-        const uint32_t first = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+        const uint32_t first = tile0 + (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
         uint32_t cx = 0, cy = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -529,7 +545,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
         // k_finish spreads evenly over waves of its own (one list position per wave of this kernel
         // would leave a wave full of such triangles with all of their entries to file).
         const bool walker = state == FAST && !single && !few;
-        if (walker) count_box(a, st);
+        if (walker) count_box(a, view, st);
         const unsigned long long wm = __ballot(walker);
         if (wm) {
             const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
@@ -564,7 +580,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
     // File the triangle: its slot number goes to the reserved position of the size class's region
     // in the bin of every tile it touches (up to four; larger ones are on the walk list).
     {
-        const uint32_t first = (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+        const uint32_t first = tile0 + (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
         const uint32_t cap = pick_region(a.bl.cap, part), off = pick_region(a.bl.off, part);
         bool over = false;
         uint32_t cx = 0, cy = 0;
@@ -617,7 +633,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, Set
             atomicOr(&a.counters->overflow, kOverflowNoClip);
         } else if (at < a.fan_capacity) {
             ClipItem it;
-            it.inst = bd.inst; it.tri = t; it.slot = slot;
+            it.inst = bd.inst; it.tri = t; it.slot = slot; it.view = view;
             a.clip_list[at] = it;
         } else {
             atomicOr(&a.counters->overflow, kOverflowClip);
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
     // one work item per workgroup (several in a loop measured slower, and a loop keeps per-thread
     // addresses alive across it, which this kernel has no registers for)
     __shared__ SetupShared sh;
-    setup_block(a, blockIdx.x, sh);
+    setup_block(a, blockIdx.x, blockIdx.y, sh); // grid: x over the work items of a view, y over the views
 }
 
 // One thread per queued triangle: Sutherland-Hodgman, then the fan of the clipped polygon goes to
@@ -648,7 +664,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
     const ClipItem it = a.clip_list[idx];
     const InstDev inst = a.insts[it.inst];
     const MeshDev mesh = a.meshes[inst.mesh];
-    const float *pvm = a.pvm + 16 * (size_t)inst.object;
+    const float *pvm = a.pvm + 16 * ((size_t)it.view * a.n_objects + inst.object);
     const uint32_t *ip = a.indices + mesh.idx_base + 3 * (size_t)it.tri;
     const uint32_t slot = it.slot, prim = inst.prim_base + it.tri;
     ClipVert poly[10], tmp[10];
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
     ShadeRec h;
     h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
     h.prim = prim;
-    const uint32_t fan_base = a.n_blocks * kSetupThreads + fan0;
+    const uint32_t fan_base = a.g.views * a.n_blocks * kSetupThreads + fan0;
     h.fan_or_ra = fan_base;
     h.tex_fan = ((uint32_t)inst.texture & 0xFFFFFFu) | ((room ? n_fan : 0u) << 24);
     a.shade[slot] = h;
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         Attr3 u = {q0.c[4] * v0.rw, q1.c[4] * v1.rw, q2.c[4] * v2.rw}, v = {q0.c[5] * v0.rw, q1.c[5] * v1.rw, q2.c[5] * v2.rw};
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
         write_records(a, rec, s2, prim, inst.texture, u, v, cr, cg, cb);
-        count_box(a, s2);
+        count_box(a, it.view, s2);
         a.walk_list[atomicAdd(&a.counters->walk_count, 1u)] = rec; // (clipping is rare: one atomic per fan triangle)
     }
 }
@@ -777,7 +793,10 @@ __device__ inline bool block_from_record(const FinishArgs &a, uint32_t rec, uint
         return false;
     cols = (uint32_t)(bx1 / kTile - bx0 / kTile) + 1u;
     rows = (uint32_t)(by1 / kTile - by0 / kTile) + 1u;
-    first = (uint32_t)(by0 / kTile - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)(bx0 / kTile);
+    // the view comes from the slot that ranks the record (its own, or its primitive's for a fan)
+    const uint32_t slots_per_view = a.n_blocks * kSetupThreads, n_slots = a.g.views * slots_per_view;
+    const uint32_t view = (rec < n_slots ? rec : a.fan_order[rec - n_slots]) / slots_per_view;
+    first = view * a.g.n_tiles + (uint32_t)(by0 / kTile - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)(bx0 / kTile);
     return true;
 }
 
@@ -850,12 +869,14 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
 {
     __shared__ unsigned long long s_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t last_tile = max(a.g.n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
-    const uint32_t chunks = max((a.g.n_tiles + kOrderChunk - 1u) / kOrderChunk, 1u);
+    const uint32_t n_tiles = total_tiles(a.g);       // of all views
+    const uint32_t last_tile = max(n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
+    const uint32_t chunks = max((n_tiles + kOrderChunk - 1u) / kOrderChunk, 1u);
+    const uint32_t n_blocks = a.n_blocks * a.g.views;
     if (blockIdx.x == 0) {
         // four counts per load, sixteen loads in flight per thread
         uint32_t sum = 0;
-        const uint32_t n4 = a.n_blocks / 4u;
+        const uint32_t n4 = n_blocks / 4u;
         const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
         for (uint32_t i = tid; i < n4; i += 16u * kFinishThreads) {
             uint4 v[16];
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
 #pragma unroll
             for (int k = 0; k < 16; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
-        if ((uint32_t)tid < a.n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
+        if ((uint32_t)tid < n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
         const uint32_t records = (uint32_t)block_sum(sum, s_part, lane, wave); // (at most 256 per work item, 2^23 work items)
         if (tid == 0) a.counters->total_records = records;
         return;
@@ -885,7 +906,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
         for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const bool on = base + (uint32_t)tid + kFinishThreads * (uint32_t)k < a.g.n_tiles;
+            const bool on = base + (uint32_t)tid + kFinishThreads * (uint32_t)k < n_tiles;
             class_take(s_hist, order_class(tile_cost(mine[k])), on, lane);
             account(tt, mine[k], on);
         }
@@ -898,7 +919,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
                 for (int k = 0; k < 8; ++k) oc[k] = a.tiles[min(other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const bool on = other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k < a.g.n_tiles;
+                    const bool on = other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k < n_tiles;
                     const uint32_t cls = order_class(tile_cost(oc[k]));
                     class_take(s_hist, cls, on, lane);
                     if (other < chunk) class_take(s_before, cls, on, lane);
@@ -918,11 +939,12 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t i = base + (uint32_t)tid + kFinishThreads * (uint32_t)k;
-            const uint32_t at = class_take(s_hist, order_class(tile_cost(mine[k])), i < a.g.n_tiles, lane);
-            if (i < a.g.n_tiles) {
+            const uint32_t at = class_take(s_hist, order_class(tile_cost(mine[k])), i < n_tiles, lane);
+            if (i < n_tiles) {
                 uint4 *dst = reinterpret_cast<uint4 *>(a.tile_launch + at);
-                dst[0] = make_uint4(i, mine[k].multi, mine[k].cnt[3], mine[k].cnt[2]);
-                dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], 0u, 0u);
+                const uint32_t view = i / a.g.n_tiles;
+                dst[0] = make_uint4(i - view * a.g.n_tiles, mine[k].multi, mine[k].cnt[3], mine[k].cnt[2]);
+                dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], view, 0u);
             }
         }
         if (chunk == 0) {
@@ -970,7 +992,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
 
 hipError_t launch_object(const ObjectArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_object, dim3(a.n / 256 + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_object, dim3(a.n / 256 + 1, a.g.views ? a.g.views : 1u), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1001,9 +1023,9 @@ hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
     if (a.debug)
-        hipLaunchKernelGGL(k_setup<true>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+        hipLaunchKernelGGL(k_setup<true>, dim3(a.n_blocks, a.g.views), dim3(kSetupThreads), 0, s, a);
     else
-        hipLaunchKernelGGL(k_setup<false>, dim3(a.n_blocks), dim3(kSetupThreads), 0, s, a);
+        hipLaunchKernelGGL(k_setup<false>, dim3(a.n_blocks, a.g.views), dim3(kSetupThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1017,7 +1039,8 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s)
 
 hipError_t launch_finish(const FinishArgs &a, hipStream_t s)
 {
-    const uint32_t chunks = a.g.n_tiles > kOrderChunk ? (a.g.n_tiles + kOrderChunk - 1u) / kOrderChunk : 1u;
+    const uint32_t n_tiles = total_tiles(a.g);
+    const uint32_t chunks = n_tiles > kOrderChunk ? (n_tiles + kOrderChunk - 1u) / kOrderChunk : 1u;
     hipLaunchKernelGGL(k_finish, dim3(1u + chunks + a.walk_blocks), dim3(kFinishThreads), 0, s, a);
     return hipGetLastError();
 }

@@ -126,19 +126,26 @@ struct FrameCounters {
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
 // leaves the clipping to k_clip.
 struct ClipItem {
-    uint32_t inst, tri, slot;
+    uint32_t inst, tri, slot, view;
 };
 
+// One launch set renders `views` views of the scene, all of the same size, each with its own camera
+// into its own image (sxe_draw: one).  View v owns tiles [v * n_tiles, (v + 1) * n_tiles) of the
+// per-tile tables and bins, setup work items and record slots [v * n_blocks, (v + 1) * n_blocks)
+// (times 256 slots), and objects [v * n_objects, (v + 1) * n_objects) of the per-object arrays.
 struct FrameGeom {
     uint32_t width, height;
     uint32_t sy0, sy1;       // scissor rows [sy0, sy1)
-    uint32_t tiles_x, tile_row0, n_tile_rows, n_tiles;
+    uint32_t tiles_x, tile_row0, n_tile_rows, n_tiles; // n_tiles: per view
     float half_w, half_h;
+    uint32_t views;
 };
+__host__ __device__ inline uint32_t total_tiles(const FrameGeom &g) { return g.n_tiles * g.views; }
 
 struct ObjectArgs {
     const float *models;
-    Mat4 pv;
+    Mat4 pv;                     // proj * view of a single view
+    const float *pv_views;       // the same per view (16 floats each) when g.views > 1, else null
     float *pvm;
     const MeshDev *meshes;
     const uint32_t *object_mesh; // mesh of every object (caller order)
@@ -198,9 +205,10 @@ struct SetupArgs {
     const MeshDev *meshes;
     const InstDev *insts;
     const BlockDesc *blocks;
-    const float *pvm;          // 16 floats per object (caller order)
+    const float *pvm;          // 16 floats per object (caller order), per view
     const uint8_t *visible;
-    uint32_t n_blocks;
+    uint32_t n_objects;
+    uint32_t n_blocks;         // per view
     uint32_t shading;
     uint32_t debug;            // kDebug* switches (development only)
     FrameGeom g;
@@ -222,9 +230,9 @@ struct SetupArgs {
 
 // What a tile's workgroup needs to start, one record per launch position (dearest tiles first).
 struct __attribute__((aligned(16))) TileLaunch {
-    uint32_t tile;
+    uint32_t tile;                 // tile number inside its view
     uint32_t late, c3, c2, c1, c0; // entries per region, in the order the tile kernel takes them
-    uint32_t pad0, pad1;
+    uint32_t view, pad1;
 };
 
 struct FinishArgs {
@@ -235,6 +243,7 @@ struct FinishArgs {
     const RastRec *rast;
     const WideRec *wide;
     const uint32_t *walk_list; // records whose triangles take their entries here, counters->walk_count of them
+    const uint32_t *fan_order; // per fan record: the order slot of its primitive (which tells its view)
     const TileCtr *tiles;      // counts as k_setup and k_clip left them
     uint32_t *late_fill;       // per tile: how many of its late entries have been placed
     TileLaunch *tile_launch;   // out
@@ -253,7 +262,8 @@ struct RasterArgs {
     const ShadeRec *shade;
     const ColorRec *color;
     const uint32_t *fan_order;  // per record past the first n_slots: the slot that ranks it
-    uint32_t n_slots;           // 256 * setup work items
+    uint32_t n_slots;           // 256 * setup work items * views
+    size_t image_stride;        // pixels from one view's image to the next (views render into consecutive images)
     const FrameCounters *counters;
     FrameCounters *host_counters; // host-visible copy of the counters, written by the first workgroup (may be null)
     const uint8_t *texels;

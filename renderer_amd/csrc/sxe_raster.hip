@@ -495,6 +495,11 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     const float dec = c_srgb_decode[tid];
     // (a frame that overflowed has no launch records: tile 0 stands in until the workgroup leaves)
     const uint32_t tile = overflow ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
+    const uint32_t view = overflow ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.z);
+    // every view renders into its own image, one behind the other
+    a.out_color += 4 * a.image_stride * view;
+    a.out_depth += a.image_stride * view;
+    if (COVERAGE) a.out_prim += a.image_stride * view;
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     const uint32_t e4 = e3 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.x);  // + class 1
     const uint32_t e5 = e4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.y);  // + class 0
     const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : e5;
-    const uint32_t *bin = a.bins + (size_t)tile * a.bl.stride;
+    const uint32_t *bin = a.bins + (size_t)(view * a.g.n_tiles + tile) * a.bl.stride;
     // start of each region minus the entries taken before it
     const uint32_t o4 = a.bl.off[4], o3 = a.bl.off[3] - e1, o2 = a.bl.off[2] - e2, o1 = a.bl.off[1] - e3, o0 = a.bl.off[0] - e4;
     {
@@ -716,7 +721,7 @@ hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 {
     if (a.g.n_tiles == 0) return hipSuccess;
     const bool dev = a.debug != 0u || a.tile_times != nullptr, many = a.n_textures > (uint32_t)kTexCache;
-    const dim3 grid(a.g.n_tiles), block(kRasterThreads);
+    const dim3 grid(total_tiles(a.g)), block(kRasterThreads); // one workgroup per tile of every view
 #define SXE_LAUNCH(C, D, M) hipLaunchKernelGGL((k_raster_shade<C, D, M>), grid, block, 0, s, a)
     if (a.out_prim) {
         if (dev) { if (many) SXE_LAUNCH(true, true, true); else SXE_LAUNCH(true, true, false); }

@@ -553,6 +553,48 @@ def test_full_size_config5_views(orc):
     assert seen > 10000
 
 
+def test_views_drawn_as_one_set_equal_views_drawn_one_by_one(orc):
+    """sxe_draw_views: the view is a grid dimension of every kernel.  A set of views (more than one
+    launch set: 70 views of the small scene) against the oracle and against update_camera + draw,
+    with near objects that reach the late-entry and clipping paths in some views."""
+    s = scenes.sphere_field_scene(60, 4, 5.0, (-14.0, -4.0), 256, 160, n_textures=2, tex_size=64, name="views")
+    w, h = s.size
+    n = 70
+    cams = scenes.orbit_cameras(n, 9, radius=3.0, target=(0.0, 0.0, -9.0))  # cameras inside the cloud of spheres
+    models = orc.to_model(s.transforms)
+    with api.HipDrawer(w, h, n_images=n, coverage=True) as d:
+        d.update_scene(s)
+        d.draw_views(cams)
+        d.sync()
+        clipped = 0
+        for v in range(n):
+            view, proj = orc.camera(cams[v:v + 1], w, h)
+            ref = orc.render(s, models, view, proj, w, h)
+            clipped += ref["stats"]["prims_clipped"]
+            got = {"color": d.read_color(v), "depth": d.read_depth(v), "prim": d.read_coverage(v)}
+            assert_frames_equal(got, ref, what="view %d of a set" % v)
+        assert clipped > 0
+        # the same through the single-view entry points, into other images; and a rotation update
+        # that is pending when the views are drawn is applied once, before all of them
+        last = d.read_color(n - 1)
+        d.update_camera(cams[3:4])
+        d.draw(0)
+        assert np.array_equal(d.read_color(0), d.read_color(3))
+        d.rotation_system(3, 0, 400.0)
+        d.draw_views(cams[:5], first_image=10)
+        t = s.transforms.copy()
+        orc.rotation_system(t, 3, 0, 400.0)
+        assert d.read_transforms().tobytes() == t.tobytes()
+        for v in range(5):
+            view, proj = orc.camera(cams[v:v + 1], w, h)
+            ref = orc.render(s, orc.to_model(t), view, proj, w, h)
+            got = {"color": d.read_color(10 + v), "depth": d.read_depth(10 + v), "prim": d.read_coverage(10 + v)}
+            assert_frames_equal(got, ref, what="rotated view %d" % v)
+        assert np.array_equal(d.read_color(n - 1), last)
+        with pytest.raises(api.SxeError):
+            d.draw_views(cams, first_image=1)  # one image short
+
+
 def test_unrendered_objects_and_two_meshes_over_three_texture_groups(orc):
     """update_drawables' draw list (src/renderer/drawer.rs:313-347,481-487): objects with
     `rendered` false are left out, the rest is drawn by texture group; meshes of different sizes."""
