@@ -164,6 +164,12 @@ inline Status decode_jpeg(const uint8_t *data, size_t size, Image &out)
                 hmax = std::max(hmax, comps[(size_t)i].h);
                 vmax = std::max(vmax, comps[(size_t)i].v);
             }
+            if (nc == 1) {
+                // A scan with one component is not interleaved (T.81 A.2.2): one 8x8 block per MCU
+                // in raster order, whatever sampling factors the frame header carries.
+                comps[0].h = comps[0].v = 1;
+                hmax = vmax = 1;
+            }
         } else if (marker == 0xC2 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC && marker != 0xC4)) {
             return err("progressive, lossless and arithmetic-coded files are not supported (baseline only)");
         } else if (marker == 0xC3) {
@@ -256,6 +262,9 @@ inline Status decode_jpeg(const uint8_t *data, size_t size, Image &out)
                         int t = 0;
                         if (!decode_symbol(br, dc[c.td], t) || t > 11) return err("bad DC code");
                         c.pred += extend(br.bits(t), t);
+                        // (a DC value of an 8-bit image fits 12 bits; anything beyond is a damaged
+                        // or crafted file, and unchecked sums would overflow)
+                        if (c.pred < -32768 || c.pred > 32767) return err("DC value out of range");
                         coef[0] = (float)(c.pred * (int)quant[c.tq][0]);
                         for (int k = 1; k < 64;) {
                             int rs = 0;

@@ -118,6 +118,16 @@ def test_jpeg_loader_against_an_independent_decoder(tmp_path):
         ref = np.asarray(Image.open(path).convert("RGBA"))
         d = np.abs(got.astype(int) - ref.astype(int))
         assert (got[..., 3] == 255).all() and d.max() <= max_diff and d.mean() <= mean_diff, (name, d.max(), d.mean())
+    # a grey file whose frame header carries sampling factors 2x2: a one-component scan is not
+    # interleaved (T.81 A.2.2), so it holds the same blocks in the same order and decodes alike
+    raw = bytearray(open(str(tmp_path / "grey.jpg"), "rb").read())
+    sof = raw.find(b"\xff\xc0")
+    assert sof > 0 and raw[sof + 9] == 1 and raw[sof + 11] == 0x11
+    raw[sof + 11] = 0x22
+    open(str(tmp_path / "grey22.jpg"), "wb").write(bytes(raw))
+    p = subprocess.run([exe, str(tmp_path / "grey22.jpg"), str(tmp_path / "grey22.rgba")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(str(tmp_path / "grey22.rgba"), "rb").read() == open(str(tmp_path / "grey.rgba"), "rb").read()
     path = str(tmp_path / "progressive.jpg")
     Image.fromarray(picture(40, 40)).save(path, "JPEG", progressive=True)
     p = subprocess.run([exe, path, str(tmp_path / "x.rgba")], capture_output=True, text=True)
