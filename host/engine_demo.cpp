@@ -5,7 +5,8 @@
 //
 // The scene file is written by tests/util.py:write_scene_file (little endian):
 //   "SXES" u32 version(1) | u32 width height n_images n_frames | f32 rotate_deg[3] | f32 camera[10]
-//   u32 n_textures { u32 path_len, path bytes, u32 w h, w*h*4 bytes }
+//   u32 n_textures { u32 path_len, path bytes, u32 w h, w*h*4 bytes }   (w = h = 0: no bytes follow,
+//                    the path names a baseline JPEG file relative to the scene file's directory)
 //   u32 n_drawables { u32 n_vertices n_indices, vertices (32 B each), indices (u32),
 //                     f32 transform[10], i32 texture (index above or -1), u32 rendered }
 // Every frame all drawables are rotated by rotate_deg (the stand-in for the Rotation system,
@@ -13,6 +14,7 @@
 // update_uniforms, update_camera, acquire_image, draw, present.  The last presented frame is
 // written out.
 #include "sxe_drawer.hpp"
+#include "sxe_jpeg.hpp"
 
 #include <cstring>
 #include <fstream>
@@ -66,6 +68,8 @@ int main(int argc, char **argv)
         Reader r;
         r.in.open(argv[1], std::ios::binary);
         if (!r.in) throw std::runtime_error(std::string("cannot open ") + argv[1]);
+        std::string scene_dir = argv[1];
+        scene_dir = scene_dir.find_last_of('/') == std::string::npos ? std::string() : scene_dir.substr(0, scene_dir.find_last_of('/') + 1);
         char magic[4];
         r.bytes(magic, 4);
         if (std::memcmp(magic, "SXES", 4) != 0 || r.get<uint32_t>() != 1u) throw std::runtime_error("not a version 1 scene file");
@@ -87,8 +91,15 @@ int main(int argc, char **argv)
             Image im;
             im.width = r.get<uint32_t>();
             im.height = r.get<uint32_t>();
-            im.rgba.resize((size_t)im.width * im.height * 4);
-            r.bytes(im.rgba.data(), im.rgba.size());
+            if (im.width == 0 && im.height == 0) {
+                // no texels in the scene file: the path names a JPEG file next to it, loaded the
+                // way TextureData::load does (image::open(path).to_rgba(), src/renderer/types.rs:158-188)
+                const Status st = load_jpeg(scene_dir + t.path, im);
+                if (!st) throw std::runtime_error(st.error);
+            } else {
+                im.rgba.resize((size_t)im.width * im.height * 4);
+                r.bytes(im.rgba.data(), im.rgba.size());
+            }
             drawer->provide_image(t.path, std::move(im));
         }
         std::vector<Drawable> world(r.get<uint32_t>());

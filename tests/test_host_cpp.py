@@ -75,12 +75,8 @@ def test_png_writer_produces_a_valid_file(tmp_path):
     assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:], (((i * 2654435761) & 0xFFFFFFFF) >> 13).astype(np.uint8).reshape(77, -1))
 
 
-def test_jpeg_loader_against_an_independent_decoder(tmp_path):
-    """include/sxe_jpeg.hpp (the texture-file loader): baseline files in the usual samplings, with
-    and without restart markers, decode to what an independent decoder gives, up to the few code
-    values by which integer inverse DCTs and chroma interpolation differ; progressive files are
-    refused.  The test images are synthetic (the reference's textures are unavailable LFS pointers)."""
-    Image = pytest.importorskip("PIL.Image")
+def build_jpeg_dump(tmp_path):
+    """A small program around sxe_host::load_jpeg: <file.jpg> <out.rgba>, prints width and height."""
     src = tmp_path / "j.cpp"
     src.write_text(
         '#include "sxe_jpeg.hpp"\n#include <iostream>\n'
@@ -95,6 +91,16 @@ def test_jpeg_loader_against_an_independent_decoder(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
                            "-L", os.path.join(ROOT, "renderer_amd"), "-lsxe_hip", "-Wl,-rpath," + os.path.join(ROOT, "renderer_amd"),
                            "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_jpeg_loader_against_an_independent_decoder(tmp_path):
+    """include/sxe_jpeg.hpp (the texture-file loader): baseline files in the usual samplings, with
+    and without restart markers, decode to what an independent decoder gives, up to the few code
+    values by which integer inverse DCTs and chroma interpolation differ; progressive files are
+    refused.  The test images are synthetic (the reference's textures are unavailable LFS pointers)."""
+    Image = pytest.importorskip("PIL.Image")
+    exe = build_jpeg_dump(tmp_path)
     rng = np.random.default_rng(1)
 
     def picture(w, h):
@@ -174,3 +180,36 @@ def test_cpp_drawer_reports_a_missing_texture_image(tmp_path):
     s.objects["texture"] = -1
     p, out, _ = run_demo(tmp_path, s)
     assert p.returncode == 1 and "update_drawables" in p.stderr and "texture" in p.stderr
+
+
+@pytest.mark.gpu
+def test_textures_loaded_from_jpeg_files_end_to_end(tmp_path, orc):
+    """TextureData::load's path (src/renderer/types.rs:158-188) end to end: the scene file names
+    baseline JPEG files, the C++ host loads them (sxe_host::load_jpeg), the frame must equal the
+    oracle's frame of the same scene with the texels that loader produced.  Synthetic pictures (the
+    reference's own textures are unavailable LFS pointers)."""
+    Image = pytest.importorskip("PIL.Image")
+    s = scenes.reference_demo_scene(n=64, seed=7, width=320, height=240)
+    exe = build_jpeg_dump(tmp_path)
+    names, texels = [], []
+    for k, t in enumerate(s.textures):
+        name = "tex%d.jpg" % k
+        Image.fromarray(t[..., :3]).save(str(tmp_path / name), "JPEG", quality=88, subsampling=(0, 2, 1)[k % 3])
+        out = str(tmp_path / ("tex%d.rgba" % k))
+        p = subprocess.run([exe, str(tmp_path / name), out], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        w, h = (int(x) for x in p.stdout.split())
+        texels.append(np.fromfile(out, np.uint8).reshape(h, w, 4))
+        assert texels[-1].shape == t.shape and not np.array_equal(texels[-1], t)  # lossy, but the same picture
+        assert np.abs(texels[-1].astype(int) - t.astype(int)).mean() < 12
+        names.append(name)
+    p, out, _ = run_demo(tmp_path, s, n_images=2, n_frames=1, texture_files=names)
+    assert p.returncode == 0, p.stderr
+    w, h = s.size
+    got = np.fromfile(out, dtype=np.uint8).reshape(h, w, 4)
+    decoded = scenes.Scene(s.vertices, s.indices, s.meshes, s.objects, s.transforms, texels, camera=s.camera, size=s.size)
+    view, proj = orc.camera(s.camera, w, h)
+    ref = orc.render(decoded, orc.to_model(s.transforms), view, proj, w, h)
+    assert np.array_equal(got, ref["color"])
+    with_original = orc.render(s, orc.to_model(s.transforms), view, proj, w, h)
+    assert not np.array_equal(got, with_original["color"])

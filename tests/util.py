@@ -136,9 +136,10 @@ def random_soup(rng, n, width, height, kinds=("tiny", "small", "medium", "large"
     return tris
 
 
-def write_scene_file(path, scene, n_images=2, n_frames=1, rotate_deg=(0.0, 0.0, 0.0)):
+def write_scene_file(path, scene, n_images=2, n_frames=1, rotate_deg=(0.0, 0.0, 0.0), texture_files=None):
     """Scene file of host/engine_demo.cpp (format described there): reference-style drawables, one
-    mesh copy per object, textures referred to by path."""
+    mesh copy per object, textures referred to by path.  With `texture_files` (one file name per
+    texture, relative to the scene file) the texels are left out and the program loads the files."""
     import struct
     w, h = scene.size
     with open(path, "wb") as f:
@@ -148,8 +149,11 @@ def write_scene_file(path, scene, n_images=2, n_frames=1, rotate_deg=(0.0, 0.0, 
         f.write(np.ascontiguousarray(scene.camera).tobytes())
         f.write(struct.pack("<I", len(scene.textures)))
         for k, t in enumerate(scene.textures):
-            name = ("textures/tex%03d.jpg" % k).encode()
+            name = (texture_files[k] if texture_files else "textures/tex%03d.jpg" % k).encode()
             f.write(struct.pack("<I", len(name)) + name)
+            if texture_files:
+                f.write(struct.pack("<2I", 0, 0))
+                continue
             f.write(struct.pack("<2I", t.shape[1], t.shape[0]))
             f.write(np.ascontiguousarray(t, dtype=np.uint8).tobytes())
         f.write(struct.pack("<I", len(scene.objects)))

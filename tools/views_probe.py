@@ -26,6 +26,7 @@ with api.HipDrawer(w, h, n_images=n_img, timing=True) as d:
         dt = time.perf_counter() - t0
     single = dt / min(n, 1024)
     print("one view per draw: %.4f ms/view, %.0f views/s" % (1e3 * single, 1.0 / single))
+    d.update_camera(cams[5:6]); d.draw(5)
     ref = d.read_color(5)
     # sets
     for rep in range(2):
