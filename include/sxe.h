@@ -135,8 +135,12 @@ const char *sxe_last_error(const sxe_ctx *ctx);
 const char *sxe_version(void);
 
 /* ---- scene: Drawer::update_drawables (src/renderer/drawer.rs:458-494) ---- */
-/* generate_images (src/renderer/drawer.rs:216-236): replaces the whole texture table.  Textures
- * must be opaque (alpha 255 everywhere), as every JPEG-derived reference texture is. */
+/* generate_images (src/renderer/drawer.rs:216-236): replaces the whole texture table.  Opaque
+ * textures (alpha 255 everywhere, as every JPEG-derived reference texture is) are shaded once per
+ * pixel.  A texture with any other alpha makes the screen tiles its triangles touch take an ordered
+ * path that depth-tests and blends every fragment in submission order (BlendState::ALPHA,
+ * src/renderer/drawer.rs:660-663): exact, much slower, and limited to 4096 bin entries per such
+ * 32x32 tile (SXE_E_CAPACITY from sxe_sync beyond). */
 int sxe_set_textures(sxe_ctx *ctx, const sxe_texture_desc *textures, uint32_t n);
 /* One mesh per drawable, drawn once, as the reference stores them (src/renderer/drawer.rs:173-193). */
 int sxe_update_drawables(sxe_ctx *ctx, const sxe_drawable *drawables, uint32_t n);

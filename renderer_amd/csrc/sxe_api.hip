@@ -139,6 +139,7 @@ struct sxe_ctx {
 
     // scene
     bool have_scene = false, have_camera = false;
+    bool blend_scene = false;       // some texture of the table has a texel with alpha below 255
     int32_t scene_max_texture = -1; // largest texture index the uploaded scene samples
     bool scene_lost_textures = false; // the texture table was replaced by one that lacks some of them
     uint32_t n_objects = 0, n_draws = 0, n_blocks = 0, n_vblocks = 0, n_meshes = 0, n_textures = 0;
@@ -627,6 +628,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.tiles = reinterpret_cast<TileCtr *>(w.tile_counters);
     sa.bins = w.bins;
     sa.bl = w.bl;
+    sa.textures = c->textab.p;
+    sa.blend_scene = c->blend_scene ? 1u : 0u;
     sa.rast = w.rast;
     sa.wide = w.wide;
     sa.shade = w.shade;
@@ -687,7 +690,9 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     // run or still changes them (development census)
     const bool direct = nt > 0 && fs.d_counters && !(c->cfg.flags & kDebugSkipAtomic);
     ra.host_counters = direct ? fs.d_counters : nullptr;
+    ra.blend_scene = c->blend_scene ? 1u : 0u;
     SXE_HIP(c, launch_raster_shade(ra, s));
+    SXE_HIP(c, launch_raster_blend(ra, s)); // (only when a texture is translucent: the tiles the kernel above left out)
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_RASTER], s));
 
     if (!direct) SXE_HIP(c, hipMemcpyAsync(fs.h_counters, w.counters, sizeof(FrameCounters), hipMemcpyDeviceToHost, s));
@@ -817,13 +822,19 @@ int retire_oldest(sxe_ctx *c)
     SXE_HIP(c, hipEventSynchronize(fs.done));
     if (fs.h_counters->overflow) {
         SXE_HIP(c, hipStreamSynchronize(c->stream));
-        bool hopeless = false; // a frame in flight that no regrowth can hold
-        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f)
-            hopeless = hopeless || (c->slots[f % kFrameSlots].h_counters->overflow & kOverflowPairs);
+        uint32_t hopeless = 0, blend_max = 0; // a frame in flight that no regrowth can hold
+        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
+            const FrameCounters &k = *c->slots[f % kFrameSlots].h_counters;
+            hopeless |= k.overflow & (kOverflowPairs | kOverflowBlend);
+            blend_max = std::max(blend_max, k.blend_max);
+        }
         if (hopeless) {
             for (FrameSlot &x : c->slots) x.pending = false;
             c->frames_retired = c->frames_enqueued;
-            return fail(c, SXE_E_CAPACITY, "frame has more than 2^32 - 1 (triangle, tile) bin entries");
+            if (hopeless & kOverflowPairs) return fail(c, SXE_E_CAPACITY, "frame has more than 2^32 - 1 (triangle, tile) bin entries");
+            return fail(c, SXE_E_CAPACITY,
+                        "a screen tile with translucent triangles holds %u bin entries: blending in submission order takes at "
+                        "most %u per tile", blend_max, kBlendMaxEntries);
         }
         for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
             FrameSlot &r = c->slots[f % kFrameSlots];
@@ -1062,21 +1073,22 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
     if (n > 65536) return fail(c, SXE_E_CAPACITY, "at most 65536 textures");
     std::vector<TexDev> tab(n);
     size_t total = 0;
+    bool any_translucent = false;
     for (uint32_t t = 0; t < n; ++t) {
         const sxe_texture_desc &d = textures[t];
         if (!d.rgba || d.width == 0 || d.height == 0 || d.width > 16384 || d.height > 16384)
             return fail(c, SXE_E_INVALID, "texture %u: bad size %ux%u or null pixels", t, d.width, d.height);
         const size_t px = (size_t)d.width * d.height;
-        for (size_t i = 0; i < px; ++i)
-            if (d.rgba[4 * i + 3] != 255)
-                return fail(c, SXE_E_INVALID,
-                            "texture %u is not opaque (pixel %zu has alpha %u): blending is resolved once per pixel, "
-                            "which equals the reference's in-order blending only for opaque texels",
-                            t, i, d.rgba[4 * i + 3]);
+        // Opaque textures (every JPEG-derived one of the reference) are shaded once per pixel: with
+        // alpha 1 the blend returns the source.  A texture with any other alpha sends the tiles its
+        // triangles touch down the ordered path.
+        bool translucent = false;
+        for (size_t i = 0; i < px && !translucent; ++i) translucent = d.rgba[4 * i + 3] != 255;
+        any_translucent = any_translucent || translucent;
         tab[t].offset = (uint32_t)total;
         tab[t].width = d.width;
         tab[t].height = d.height;
-        tab[t].pad = 0;
+        tab[t].flags = translucent ? kTexTranslucent : 0u;
         total += px;
         if (total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
     }
@@ -1089,6 +1101,7 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
                              4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice));
     if (n) SXE_HIP(c, hipMemcpy(c->textab.p, tab.data(), n * sizeof(TexDev), hipMemcpyHostToDevice));
     c->n_textures = n;
+    c->blend_scene = any_translucent;
     // The scene's texture indices were checked against the table of its upload.  A table that no
     // longer holds all of them must not be sampled with them: the scene has to be uploaded again.
     if (c->have_scene && c->scene_max_texture >= (int32_t)n) {
@@ -1338,6 +1351,9 @@ int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
     const FrameCounters &k = *fs.h_counters;
     if (k.overflow) {
         c->images[image_index].drawn = false;
+        if (k.overflow & kOverflowBlend)
+            return fail(c, SXE_E_CAPACITY, "a screen tile with translucent triangles holds %u bin entries: blending in submission "
+                                           "order takes at most %u per tile", k.blend_max, kBlendMaxEntries);
         if (k.overflow & kOverflowBins)
             return fail(c, SXE_E_CAPACITY,
                         "frame needs bins of %u/%u/%u/%u/%u entries per tile (size classes 0-3, late entries), the static work "

@@ -373,13 +373,23 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, const Scr
 }
 
 // One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
-__device__ inline void count_box(const SetupArgs &a, uint32_t view, const ScreenTri &s)
+__device__ inline void count_box(const SetupArgs &a, uint32_t view, const ScreenTri &s, bool translucent)
 {
     const int32_t tx0 = s.px0 / kTile, tx1 = s.px1 / kTile;
     const int32_t ty0 = s.py0 / kTile - (int32_t)a.g.tile_row0, ty1 = s.py1 / kTile - (int32_t)a.g.tile_row0;
     TileCtr *tiles = a.tiles + (size_t)view * a.g.n_tiles;
     for (int32_t ty = ty0; ty <= ty1; ++ty)
-        for (int32_t tx = tx0; tx <= tx1; ++tx) atomicAdd(&tiles[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx].multi, 1u);
+        for (int32_t tx = tx0; tx <= tx1; ++tx) {
+            TileCtr &t = tiles[(uint32_t)ty * a.g.tiles_x + (uint32_t)tx];
+            atomicAdd(&t.multi, 1u);
+            if (translucent) atomicOr(&t.flags, kTileBlend);
+        }
+}
+
+// Does a triangle with this texture need its fragments blended in order?
+__device__ inline bool translucent_texture(const SetupArgs &a, int32_t texture)
+{
+    return a.blend_scene && a.shading != SXE_SHADE_VERTEX_COLOR && (a.textures[texture].flags & kTexTranslucent);
 }
 
 // One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object
@@ -421,6 +431,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
         return;
     }
     const float *pvm = a.pvm + 16 * vobject;
+    const bool translucent = translucent_texture(a, bd.texture); // (the same for the whole work item)
     if (cached) {
         for (uint32_t i = (uint32_t)tid; i < bd.vtx_n; i += kSetupThreads) {
             const sxe_vertex &w = a.vertices[bd.vtx_base + bd.vtx_lo + i];
@@ -536,7 +547,10 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
                 }
                 pending &= ~same;
             }
-            if (has && (uint32_t)lane == (who4[j] & 255u)) raw4[j] = atomicAdd(&a.tiles[counter >> 2].cnt[counter & 3u], count_j);
+            if (has && (uint32_t)lane == (who4[j] & 255u)) {
+                raw4[j] = atomicAdd(&a.tiles[counter >> 2].cnt[counter & 3u], count_j);
+                if (translucent) atomicOr(&a.tiles[counter >> 2].flags, kTileBlend);
+            }
             if (++cx > cols_m1) { cx = 0; ++cy; }
         }
     }
@@ -545,7 +559,7 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
         // k_finish spreads evenly over waves of its own (one list position per wave of this kernel
         // would leave a wave full of such triangles with all of their entries to file).
         const bool walker = state == FAST && !single && !few;
-        if (walker) count_box(a, view, st);
+        if (walker) count_box(a, view, st, translucent);
         const unsigned long long wm = __ballot(walker);
         if (wm) {
             const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         Attr3 u = {q0.c[4] * v0.rw, q1.c[4] * v1.rw, q2.c[4] * v2.rw}, v = {q0.c[5] * v0.rw, q1.c[5] * v1.rw, q2.c[5] * v2.rw};
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
         write_records(a, rec, s2, prim, inst.texture, u, v, cr, cg, cb);
-        count_box(a, it.view, s2);
+        count_box(a, it.view, s2, translucent_texture(a, inst.texture));
         a.walk_list[atomicAdd(&a.counters->walk_count, 1u)] = rec; // (clipping is rare: one atomic per fan triangle)
     }
 }
@@ -846,11 +860,13 @@ __device__ inline void bin_walk(const FinishArgs &a, bool walk, uint32_t rec, ui
 struct TileTotals {
     unsigned long long pairs;
     uint32_t need[kBinRegions];
+    uint32_t blend_max; // most entries of any tile that takes the ordered path
 };
 __device__ inline void account(TileTotals &tt, const TileCtr &t, bool on)
 {
     if (!on) return;
     tt.pairs += (unsigned long long)bin_reserved(t) + t.multi;
+    if (t.flags & kTileBlend) tt.blend_max = max(tt.blend_max, bin_size(t));
 #pragma unroll
     for (int r = 0; r < kSizeClasses; ++r) tt.need[r] = max(tt.need[r], t.cnt[r]);
     tt.need[kSizeClasses] = max(tt.need[kSizeClasses], t.multi);
@@ -899,6 +915,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
         __syncthreads();
         TileTotals tt;
         tt.pairs = 0;
+        tt.blend_max = 0;
 #pragma unroll
         for (int r = 0; r < kBinRegions; ++r) tt.need[r] = 0;
         TileCtr mine[8]; // this chunk's tiles: their counters are read once (all eight loads in flight together)
@@ -944,7 +961,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
                 uint4 *dst = reinterpret_cast<uint4 *>(a.tile_launch + at);
                 const uint32_t view = i / a.g.n_tiles;
                 dst[0] = make_uint4(i - view * a.g.n_tiles, mine[k].multi, mine[k].cnt[3], mine[k].cnt[2]);
-                dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], view, 0u);
+                dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], view, mine[k].flags);
             }
         }
         if (chunk == 0) {
@@ -952,9 +969,12 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
             uint32_t need[kBinRegions];
 #pragma unroll
             for (int r = 0; r < kBinRegions; ++r) need[r] = block_max(tt.need[r], s_part, lane, wave);
+            const uint32_t blend_max = block_max(tt.blend_max, s_part, lane, wave);
             if (tid == 0) {
+                a.counters->blend_max = blend_max;
                 a.counters->total_pairs = (uint32_t)min(pairs, 0xFFFFFFFFull);
                 uint32_t flags = pairs > 0xFFFFFFFFull ? kOverflowPairs | kOverflowBins : 0u; // beyond any bin array
+                if (blend_max > kBlendMaxEntries) flags |= kOverflowBlend;
 #pragma unroll
                 for (int r = 0; r < kBinRegions; ++r) {
                     a.counters->need[r] = need[r];

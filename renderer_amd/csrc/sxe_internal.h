@@ -33,6 +33,12 @@ constexpr uint32_t kDebugMask = 63u << 26;
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
 constexpr uint32_t kOverflowNoClip = 4u; // a triangle needs clipping in a frame enqueued without the clip kernel
 constexpr uint32_t kOverflowPairs = 8u;  // more than 2^32 - 1 (triangle, tile) pairs: beyond any bin array
+constexpr uint32_t kOverflowBlend = 16u; // a tile with translucent triangles holds more entries than the ordered path sorts
+// Tiles that hold a triangle with a translucent texture are rendered by k_raster_blend: every
+// fragment is depth-tested and blended in submission order (BlendState::ALPHA,
+// src/renderer/drawer.rs:660-663), which takes the tile's entries sorted; at most this many.
+constexpr uint32_t kBlendMaxEntries = 4096;
+constexpr uint32_t kTileBlend = 1u;      // TileCtr::flags
 
 struct MeshDev {
     uint32_t vtx_base, n_vtx, idx_base, n_tri;
@@ -66,8 +72,10 @@ struct VBlockDesc { // work item of the vertex kernel: up to 1024 consecutive ve
 
 struct TexDev {
     uint32_t offset; // first texel in the pooled texel buffer
-    uint32_t width, height, pad;
+    uint32_t width, height;
+    uint32_t flags;  // kTexTranslucent
 };
+constexpr uint32_t kTexTranslucent = 1u; // some texel has alpha below 255: fragments must be blended in submission order
 
 // Record storage.  Setup workgroup b owns slots [256 b, 256 b + 256) and fills them from the front
 // in submission order, so a slot number orders triangles as they were submitted.  Triangles cut by
@@ -120,7 +128,8 @@ struct FrameCounters {
     uint32_t clip_count;    // triangles handed to the clip kernel
     uint32_t walk_count;    // triangles that take their bin entries in k_finish (entries of walk_list)
     uint32_t need[5];       // per bin region: the largest number of entries any tile has for it
-    uint32_t pad[5];        // development counters (box census)
+    uint32_t blend_max;     // most entries of any tile that takes the ordered (blending) path
+    uint32_t pad[4];        // development counters (box census)
 };
 
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
@@ -188,7 +197,9 @@ __host__ __device__ inline uint32_t pick_region(const uint32_t (&v)[kBinRegions]
 }
 struct __attribute__((aligned(16))) TileCtr {
     uint32_t cnt[kSizeClasses];
-    uint32_t multi, pad0, pad1, pad2;
+    uint32_t multi;
+    uint32_t flags; // kTileBlend
+    uint32_t pad1, pad2;
 };
 __host__ __device__ inline uint32_t bin_reserved(const TileCtr &t) { return t.cnt[0] + t.cnt[1] + t.cnt[2] + t.cnt[3]; }
 __host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return bin_reserved(t) + t.multi; }
@@ -216,6 +227,8 @@ struct SetupArgs {
     TileCtr *tiles;
     uint32_t *bins;
     BinLayout bl;
+    const TexDev *textures;    // read only when blend_scene is set
+    uint32_t blend_scene;      // some texture of the table is translucent
     RastRec *rast;
     WideRec *wide;
     ShadeRec *shade;
@@ -232,7 +245,8 @@ struct SetupArgs {
 struct __attribute__((aligned(16))) TileLaunch {
     uint32_t tile;                 // tile number inside its view
     uint32_t late, c3, c2, c1, c0; // entries per region, in the order the tile kernel takes them
-    uint32_t view, pad1;
+    uint32_t view;
+    uint32_t flags;                // the tile's TileCtr::flags
 };
 
 struct FinishArgs {
@@ -276,6 +290,7 @@ struct RasterArgs {
     uint32_t clear_code;  // encoded clear colour, little-endian RGBA
     uint32_t shading;
     uint32_t debug;
+    uint32_t blend_scene; // tiles flagged kTileBlend are left to k_raster_blend
 };
 
 constexpr int kMaxDevices = 64; // device ordinals the library keeps per-device state for
@@ -294,5 +309,6 @@ hipError_t launch_setup(const SetupArgs &a, hipStream_t s);
 hipError_t launch_clip(const SetupArgs &a, hipStream_t s);
 hipError_t launch_finish(const FinishArgs &a, hipStream_t s);
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s);
+hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s);
 
 } // namespace sxe

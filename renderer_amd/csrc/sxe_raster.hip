@@ -496,6 +496,8 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     // (a frame that overflowed has no launch records: tile 0 stands in until the workgroup leaves)
     const uint32_t tile = overflow ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
     const uint32_t view = overflow ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.z);
+    // a tile with translucent triangles is rendered by k_raster_blend, in submission order
+    if (a.blend_scene && !overflow && ((uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.w) & kTileBlend)) return;
     // every view renders into its own image, one behind the other
     a.out_color += 4 * a.image_stride * view;
     a.out_depth += a.image_stride * view;
@@ -731,6 +733,183 @@ hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
         else     { if (many) SXE_LAUNCH(false, false, true); else SXE_LAUNCH(false, false, false); }
     }
 #undef SXE_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered path: tiles that hold a triangle with a translucent texture
+// ------------------------------------------------------------------------------------------
+
+// texture(sampler2D, uv) with all four channels: colour decoded from sRGB before filtering, alpha
+// as UNORM8 (standard.frag:12 on an Rgba8Srgb image, src/renderer/types.rs:186).
+__device__ inline void filter_quad_rgba(const float *dec, const float *un, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11,
+                                        float ax, float ay, float out[4])
+{
+    for (int k = 0; k < 4; ++k) {
+        const int sh = 8 * k;
+        const float *lut = k < 3 ? dec : un;
+        const float c00 = lut[(t00 >> sh) & 255], c10 = lut[(t10 >> sh) & 255];
+        const float c01 = lut[(t01 >> sh) & 255], c11 = lut[(t11 >> sh) & 255];
+        const float top = c00 + ax * (c10 - c00);
+        const float bot = c01 + ax * (c11 - c01);
+        out[k] = top + ay * (bot - top);
+    }
+}
+
+// One workgroup per flagged tile.  The tile's entries are sorted by submission order (a record's
+// rank, then its record number: the fan triangles of a clipped primitive share a rank and follow
+// each other as the fan lists them), then every thread takes them one after the other against the
+// four pixels it owns: coverage, depth test Less with depth write, shading, and
+// BlendState::ALPHA over what the sRGB8 target holds (src/renderer/drawer.rs:660-663,698-705),
+// exactly as the fixed-function pipeline does it one fragment at a time.  Slow next to
+// k_raster_shade (every entry is visited by every wave whose rows its box touches), and only
+// used where the result depends on the order.
+template <bool COVERAGE>
+__global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
+{
+    __shared__ unsigned long long s_key[kBlendMaxEntries];
+    __shared__ __attribute__((aligned(16))) uint32_t s_enc[kEncPadded];
+    __shared__ float s_dec[256], s_un[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.counters->overflow) return;
+    const uint4 launch = reinterpret_cast<const uint4 *>(a.tile_launch)[2 * blockIdx.x];
+    const uint4 launch2 = reinterpret_cast<const uint4 *>(a.tile_launch)[2 * blockIdx.x + 1];
+    if (!((uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.w) & kTileBlend)) return;
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
+    const uint32_t view = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.z);
+    a.out_color += 4 * a.image_stride * view;
+    a.out_depth += a.image_stride * view;
+    if (COVERAGE) a.out_prim += a.image_stride * view;
+    for (int i = tid; i < kEncPadded; i += kRasterThreads) s_enc[i] = reinterpret_cast<const uint32_t *>(g_srgb_encode)[i];
+    s_dec[tid] = c_srgb_decode[tid];
+    s_un[tid] = c_unorm8[tid];
+    const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
+    const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
+    const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
+    const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
+
+    // the tile's entries, region by region, with their sort keys
+    const uint32_t cnt[kBinRegions] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.x),
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.w), (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z),
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y)}; // classes 0-3, late
+    const uint32_t *bin = a.bins + (size_t)(view * a.g.n_tiles + tile) * a.bl.stride;
+    uint32_t n = 0;
+#pragma unroll
+    for (int r = 0; r < kBinRegions; ++r) {
+        for (uint32_t i = (uint32_t)tid; i < cnt[r]; i += kRasterThreads) {
+            const uint32_t rec = bin[a.bl.off[r] + i];
+            const uint32_t order = rec < a.n_slots ? rec : a.fan_order[rec - a.n_slots];
+            if (n + i < kBlendMaxEntries) s_key[n + i] = ((unsigned long long)order << 32) | rec;
+        }
+        n += cnt[r];
+    }
+    n = min(n, kBlendMaxEntries); // (k_finish has flagged the frame if a tile holds more)
+    uint32_t n_pow2 = 1;
+    while (n_pow2 < n) n_pow2 <<= 1;
+    for (uint32_t i = n + (uint32_t)tid; i < n_pow2; i += kRasterThreads) s_key[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n_pow2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = (uint32_t)tid; i < n_pow2; i += kRasterThreads) {
+                const uint32_t partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long x = s_key[i], y = s_key[partner];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        s_key[i] = y;
+                        s_key[partner] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+    // a thread owns pixels (lane & 31, 2 * wave + (lane >> 5) + 8 k), k = 0..3: a wave owns two rows out of every eight
+    const int32_t lx = lane & 31, ly0 = 2 * wave + (lane >> 5);
+    float depth[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    uint32_t code[4] = {a.clear_code, a.clear_code, a.clear_code, a.clear_code};
+    uint32_t prim[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
+    for (uint32_t e = 0; e < n; ++e) {
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_key[e]);
+        const RastRec r = a.rast[rec];
+        if (r.x0 == kNoRaster) continue;
+        const Tri t = unpack_tri(r, a.wide, rec);
+        int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+        if (!pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1)) continue;
+        const ShadeRec h = a.shade[rec];
+        // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 with the top-left rule as a bias
+        const long long ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1, ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2, ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+        const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
+                        b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int32_t row = tpy + 2 * wave + 8 * k; // the wave's rows of this round: row, row + 1
+            if (row + 1 < by0 || row > by1) continue;   // (the same for the whole wave)
+            const int32_t px = tpx + lx, py = tpy + ly0 + 8 * k;
+            if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
+            const long long sx = 256ll * px + 128, sy = 256ll * py + 128;
+            const long long E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1);
+            const long long E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2);
+            const long long E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0);
+            if (((E0 - b0) | (E1 - b1) | (E2 - b2)) < 0) continue;
+            const float l1 = (float)E1 * r.rA, l2 = (float)E2 * r.rA;
+            const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
+            if (!(z < 1.0f)) continue;      // can never be Less than the cleared 1.0
+            if (!(z < depth[k])) continue;  // Comparison::Less, src/renderer/drawer.rs:700
+            depth[k] = z;
+            prim[k] = h.prim;
+            const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
+            const float riw = 1.0f / iw;
+            float src[4];
+            if (a.shading == SXE_SHADE_VERTEX_COLOR) {
+                const ColorRec c = a.color[rec];
+                src[0] = ((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw;
+                src[1] = ((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw;
+                src[2] = ((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw;
+                src[3] = 1.0f;
+            } else {
+                const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
+                const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
+                const TexDev td = a.textures[h.tex_fan & 0xFFFFFFu];
+                const TexelQuad tq = texel_quad(td, u, v);
+                filter_quad_rgba(s_dec, s_un, texels[tq.i00], texels[tq.i10], texels[tq.i01], texels[tq.i11], tq.ax, tq.ay, src);
+                if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
+                    const ColorRec c = a.color[rec];
+                    src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
+                    src[1] = (((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw) * src[1];
+                    src[2] = (((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw) * src[2];
+                }
+            }
+            // BlendState::ALPHA on an sRGB8 target: the destination is what the target holds
+            const float sa = src[3], ia = 1.0f - sa;
+            const float dr = s_dec[code[k] & 255u], dg = s_dec[(code[k] >> 8) & 255u], db = s_dec[(code[k] >> 16) & 255u];
+            const float da = s_un[code[k] >> 24];
+            const uint32_t cr = srgb_encode_lds(s_enc, src[0] * sa + dr * ia);
+            const uint32_t cg = srgb_encode_lds(s_enc, src[1] * sa + dg * ia);
+            const uint32_t cb = srgb_encode_lds(s_enc, src[2] * sa + db * ia);
+            code[k] = cr | (cg << 8) | (cb << 16) | (unorm8_encode(sa + da * ia) << 24);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int32_t px = tpx + lx, py = tpy + ly0 + 8 * k;
+        if (px > cx1 || py < cy0 || py > cy1) continue;
+        const size_t p = (size_t)(__umul24((uint32_t)py, a.g.width) + (uint32_t)px);
+        reinterpret_cast<uint32_t *>(a.out_color)[p] = code[k];
+        a.out_depth[p] = depth[k];
+        if (COVERAGE) a.out_prim[p] = prim[k];
+    }
+}
+
+hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s)
+{
+    if (a.g.n_tiles == 0 || !a.blend_scene) return hipSuccess;
+    const dim3 grid(total_tiles(a.g)), block(kRasterThreads);
+    if (a.out_prim)
+        hipLaunchKernelGGL(k_raster_blend<true>, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(k_raster_blend<false>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -113,6 +113,19 @@ def checker_texture(size, seed):
     return t
 
 
+def translucent_texture(size, seed):
+    """The checker of checker_texture with alpha: one colour of the checker half transparent, a
+    fully transparent stripe, and alpha ramps in between (every blending regime in one texture)."""
+    t = checker_texture(size, seed)
+    y, x = np.mgrid[0:size, 0:size]
+    chk = ((x // 8 + y // 8) & 1).astype(bool)
+    alpha = np.where(chk, 128, 255)
+    alpha = np.where((y * 4 // size) == 1, (x * 255) // max(size - 1, 1), alpha)  # a ramp from clear to solid
+    alpha = np.where((x * 8 // size) == 5, 0, alpha)                               # a clear stripe
+    t[..., 3] = alpha.astype(np.uint8)
+    return t
+
+
 def _single_mesh_scene(v, idx, transforms, textures_of, textures, **kw):
     meshes = np.array([(0, len(v), 0, len(idx))], dtype=MESH)
     objects = np.zeros(len(transforms), dtype=OBJECT)

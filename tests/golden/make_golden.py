@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates the golden fixtures from the CPU oracle:  python tests/golden/make_golden.py
+"""Regenerates the golden fixtures from the CPU oracle:  python tests/golden/make_golden.py [fixture.npz ...]
 
 The reference ships no golden images and cannot run offline, so these vectors are outputs of the
 oracle (itself pinned by tests/test_oracle_math.py and tests/test_oracle_raster.py); they freeze
@@ -28,6 +28,8 @@ def save(name, scene, models, view, proj, out, extra=None):
     for i, t in enumerate(scene.textures):
         d["texture%d" % i] = t
     d.update(extra or {})
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        return  # (only the fixtures named on the command line are rewritten)
     np.savez_compressed(os.path.join(HERE, name), **d)
     print(name, out["stats"])
 
@@ -58,6 +60,12 @@ def main():
     m = oracle.to_model(s.transforms)
     v, p = oracle.camera(cam, 128, 96)
     save("spheres_cam_128x96.npz", s, m, v, p, oracle.render(s, m, v, p, 128, 96))
+    # 5. the cube with a translucent texture: fragments blended in submission order (BlendState::ALPHA)
+    s = scenes.cube_scene(96, 72)
+    s.textures = [scenes.translucent_texture(64, 3)]
+    m = oracle.to_model(s.transforms)
+    v, p = oracle.camera(s.camera, 96, 72)
+    save("blend_cube_96x72.npz", s, m, v, p, oracle.render(s, m, v, p, 96, 72))
 
 
 if __name__ == "__main__":

@@ -402,11 +402,6 @@ def test_error_behaviour(orc):
         with pytest.raises(api.SxeError) as e:  # drawable without a texture (the reference panics: drawer.rs:317)
             d.update_drawables(s.drawables())
         assert e.value.code == api.E_INVALID and "texture" in str(e.value)
-        translucent = s.textures[0].copy()
-        translucent[3, 3, 3] = 128
-        with pytest.raises(api.SxeError) as e:
-            d.set_textures([translucent])
-        assert e.value.code == api.E_INVALID and "opaque" in str(e.value)
         d.update_scene(s)
         with pytest.raises(api.SxeError) as e:
             d.draw(0)  # no camera yet
@@ -693,3 +688,88 @@ def test_sort_first_pipeline_on_one_rank(orc):
         ref = orc.render(s, orc.to_model(t), view, proj, w, h)
         assert np.array_equal(frame.cpu().numpy(), ref["color"])
         assert np.array_equal(d.read_color((n - 1) & 1), ref["color"])
+
+
+# ---- BlendState::ALPHA with translucent textures (src/renderer/drawer.rs:660-663) ----
+
+def test_translucent_textures_are_blended_in_submission_order(orc):
+    """Textures with alpha: the tiles their triangles touch depth-test and blend fragment by fragment
+    in submission order; tiles with opaque triangles only keep the fast path.  Cube, sphere field
+    with two opaque and two translucent textures, a clip-space soup with clipped fans."""
+    c = scenes.cube_scene(320, 240)
+    c.textures = [scenes.translucent_texture(128, 3)]
+    ref = render_oracle(orc, c)
+    got = render_hip(c)
+    assert_frames_equal(got, ref, what="translucent cube")
+    assert (ref["color"][..., 3] != 255).sum() == 0  # over an opaque clear colour alpha stays 255 ...
+    opaque = scenes.cube_scene(320, 240)
+    assert not np.array_equal(render_oracle(orc, opaque)["color"], ref["color"])  # ... but the colours show through
+
+    s = scenes.config_scene(2, scale=0.4)
+    s.textures = [s.textures[0], scenes.translucent_texture(256, 5), s.textures[2], scenes.translucent_texture(64, 6)]
+    ref = render_oracle(orc, s, threads=8)
+    got = render_hip(s)
+    assert_frames_equal(got, ref, what="spheres, two of four textures translucent")
+    for shading in (1, 2):
+        ref = render_oracle(orc, s, shading=shading)
+        got = render_hip(s, shading=shading)
+        assert_frames_equal(got, ref, what="translucent, shading mode %d" % shading)
+
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(31)
+    w, h = 200, 120
+    soup = soup_scene(random_soup(rng, 900, w, h), width=w, height=h, objects_split=[300, 600], tex_ids=[0, 1],
+                      textures=[scenes.checker_texture(64, 5), scenes.translucent_texture(64, 8)])
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    models = np.tile(ident, (2, 1))
+    ref = orc.render(soup, models, ident, ident, w, h)
+    assert ref["stats"]["prims_clipped"] > 30
+    got = render_hip(soup, models=models, view=ident, proj=ident)
+    assert_frames_equal(got, ref, what="translucent soup")
+    # clear colour with alpha below one: the target's alpha channel takes part
+    clear = (0.1, 0.3, 0.5, 0.25)
+    with api.HipDrawer(320, 240, coverage=True, clear=clear) as d:
+        d.update_scene(c)
+        d.update_camera(c.camera)
+        d.draw(0)
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+    ref = render_oracle(orc, c, clear=clear)
+    assert_frames_equal(got, ref, what="translucent cube over a translucent clear colour")
+    assert len(np.unique(ref["color"][..., 3])) > 3 and ref["color"][0, 0, 3] == 64
+
+
+def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
+    from tests.util import soup_scene
+    # a set of views with a translucent texture
+    s = scenes.sphere_field_scene(20, 4, 5.0, (-14.0, -4.0), 160, 96, n_textures=2, tex_size=64, name="views")
+    s.textures = [s.textures[0], scenes.translucent_texture(64, 9)]
+    cams = scenes.orbit_cameras(5, 9, radius=12.0, target=(0.0, 0.0, -9.0))
+    models = orc.to_model(s.transforms)
+    with api.HipDrawer(160, 96, n_images=5, coverage=True) as d:
+        d.update_scene(s)
+        d.draw_views(cams)
+        for v in range(5):
+            view, proj = orc.camera(cams[v:v + 1], 160, 96)
+            ref = orc.render(s, models, view, proj, 160, 96)
+            got = {"color": d.read_color(v), "depth": d.read_depth(v), "prim": d.read_coverage(v)}
+            assert_frames_equal(got, ref, what="translucent view %d" % v)
+    # more than 4096 entries in a tile that needs ordering: refused, not rendered wrong
+    rng = np.random.default_rng(77)
+    n = 32000  # about 6000 surviving entries in each of the four tiles around the centre
+    tris = np.zeros((n, 3, 3), np.float32)
+    tris[..., :2] = rng.uniform(-0.2, 0.2, (n, 1, 2)) + rng.uniform(-0.03, 0.03, (n, 3, 2))
+    tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
+    dense = soup_scene(tris, width=128, height=128, textures=[scenes.translucent_texture(64, 2)])
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    with api.HipDrawer(128, 128) as d:
+        d.update_scene(dense)
+        d.update_camera_matrices(ident, ident)
+        d.draw(0)
+        with pytest.raises(api.SxeError) as e:
+            d.sync()
+        assert e.value.code == api.E_CAPACITY and "submission order" in str(e.value)
+        d.set_textures([scenes.checker_texture(64, 2)])  # the same scene with an opaque texture is fine
+        d.update_scene(soup_scene(tris, width=128, height=128, textures=[scenes.checker_texture(64, 2)]))
+        d.draw(0)
+        d.sync()
+        assert (d.read_depth(0) < 1.0).sum() > 100
