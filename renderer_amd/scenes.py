@@ -205,6 +205,77 @@ def mixed_scene(n=40, seed=21, width=640, height=360):
                  size=(width, height), name="mixed-meshes-groups")
 
 
+class Quad:
+    """The 2-D UI primitive (src/primitives/two_d/quad.rs:12-60): a rectangle given by how far its
+    sides lie from the centre of its parent, in units where the parent spans -1..1 (no parent: the
+    whole target in NDC).  Drawn by the UI pipeline: positions passed through unchanged
+    (ui.vert:11-15), vertex colour times texture (ui.frag:12)."""
+
+    def __init__(self, key, top, left, bottom, right, parent=None, rendered=True):
+        self.key, self.rendered, self.children = key, rendered, []
+        # calculate_absolute_vertices (quad.rs:76-121); float32 step by step, as the reference computes
+        f = np.float32
+        if parent is None:
+            plx, pux, ply, puy = f(-1.0), f(1.0), f(-1.0), f(1.0)
+        else:
+            lo, up = parent.vertices[0]["pos"], parent.vertices[2]["pos"]
+            plx, pux, ply, puy = f(lo[0]), f(up[0]), f(lo[1]), f(up[1])
+        x_range = f(pux - plx)
+        x_half = f(f(x_range / f(2.0)) + plx)
+        y_range = f(puy - ply)
+        y_half = f(f(y_range / f(2.0)) + ply)
+
+        def dist(rng, rel):  # calculate_normalized_distance: |rel / 2 * range|
+            return f(abs(f(f(f(rel) / f(2.0)) * rng)))
+        lower_x, upper_x = f(x_half - dist(x_range, left)), f(x_half + dist(x_range, right))
+        lower_y, upper_y = f(y_half - dist(y_range, bottom)), f(y_half + dist(y_range, top))
+        self.vertices = np.zeros(4, dtype=VERTEX)
+        corners = [(lower_x, lower_y), (upper_x, lower_y), (upper_x, upper_y), (lower_x, upper_y)]
+        colours = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1)]
+        uvs = [(0, 0), (1, 0), (1, 1), (0, 1)]
+        for k in range(4):
+            self.vertices[k]["pos"] = (corners[k][0], corners[k][1], 0.0)
+            self.vertices[k]["color"] = colours[k]
+            self.vertices[k]["uv"] = uvs[k]
+        self.indices = np.array([0, 1, 2, 2, 3, 0], dtype=np.uint32)
+
+    def with_children(self, children):
+        self.children = list(children)
+        return self
+
+    def quads(self):
+        """This quad and its descendants in the order Quad::meshes lists them (quad.rs:123-136)."""
+        out = [self]
+        for c in self.children:
+            out += c.quads()
+        return out
+
+
+def esc_menu():
+    """EscMenu::new (src/primitives/two_d/widget.rs:16-26): an unrendered box with two children."""
+    main_box = Quad("escmenu", 0.5, -0.5, 0.5, 0.5)
+    child1 = Quad("escmenu_child1", 0.7, -0.85, 0.3, 0.85, main_box)
+    child2 = Quad("escmenu_child2", 0.0, -0.5, -0.9, 0.3, main_box)
+    main_box.rendered = False
+    return main_box.with_children([child1, child2])
+
+
+def ui_scene(root, textures, texture_of=None, width=320, height=240):
+    """A widget's quads as drawables for the UI pipeline: one mesh per quad (Quad::meshes), identity
+    transforms; render it with identity view and projection matrices and the colour-times-texture
+    shading mode, which is what ui.vert / ui.frag compute."""
+    quads = root.quads()
+    vertices = np.concatenate([q.vertices for q in quads])
+    indices = np.concatenate([q.indices for q in quads])  # mesh-local
+    meshes = np.array([(4 * i, 4, 6 * i, 6) for i in range(len(quads))], dtype=MESH)
+    objects = np.zeros(len(quads), dtype=OBJECT)
+    objects["mesh"] = np.arange(len(quads))
+    objects["texture"] = 0 if texture_of is None else texture_of
+    objects["rendered"] = [1 if q.rendered else 0 for q in quads]
+    t = np.ascontiguousarray(api.identity_transforms(1).repeat(len(quads)))
+    return Scene(vertices, indices, meshes, objects, t, textures, size=(width, height), name="ui-quads")
+
+
 def config_scene(cfg, scale=1.0):
     """The benchmark configurations. `scale` < 1 shrinks object count and frame size together
     for parity tests the CPU oracle can finish in seconds."""

@@ -773,3 +773,20 @@ def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
         d.draw(0)
         d.sync()
         assert (d.read_depth(0) < 1.0).sum() > 100
+
+
+def test_ui_quad_layer(orc):
+    """The UI pipeline (ui.vert:11-15, ui.frag:12) on the widget of src/primitives/two_d/widget.rs:16-26:
+    positions passed through (identity matrices), vertex colour times texture; the unrendered main
+    box is skipped, overlapping quads at depth 0 keep the first one drawn."""
+    root = scenes.esc_menu()
+    s = scenes.ui_scene(root, [scenes.checker_texture(64, 4), scenes.translucent_texture(64, 7)], texture_of=[0, 0, 1],
+                        width=640, height=480)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    models = np.tile(ident, (3, 1))
+    for tex_of in ([0, 0, 0], [0, 0, 1]):  # opaque; the second child translucent (ordered path)
+        s.objects["texture"] = tex_of
+        ref = orc.render(s, models, ident, ident, 640, 480, shading=2)
+        got = render_hip(s, view=ident, proj=ident, shading=2, use_drawables=True)
+        assert (ref["prim"] != 0xFFFFFFFF).sum() > 30000
+        assert_frames_equal(got, ref, what="ui quads, textures %s" % tex_of)

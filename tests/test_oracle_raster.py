@@ -212,3 +212,32 @@ def test_draw_order_groups_by_texture(orc):
     with pytest.raises(ValueError):
         s.objects["texture"][0] = 7
         render(orc, s)
+
+
+def test_ui_quads_follow_the_reference_layout(orc):
+    """Quad::calculate_absolute_vertices (src/primitives/two_d/quad.rs:76-121) and EscMenu::new
+    (widget.rs:16-26): known corner coordinates, and the UI pipeline (ui.vert:11-15 passes positions
+    through, ui.frag:12 multiplies vertex colour and texture) drawn by the oracle."""
+    from renderer_amd import scenes
+    root = scenes.esc_menu()
+    q = root.quads()
+    assert [x.key for x in q] == ["escmenu", "escmenu_child1", "escmenu_child2"] and not q[0].rendered
+    # the main box: 0.5 of the half range to every side of the centre
+    assert np.allclose(q[0].vertices["pos"][[0, 2], :2], [[-0.5, -0.5], [0.5, 0.5]], atol=0)
+    # first child inside (-0.5..0.5)^2: x -0.425..0.425, y -0.15..0.35
+    assert np.allclose(q[1].vertices["pos"][[0, 2], :2], [[-0.425, -0.15], [0.425, 0.35]], atol=1e-7)
+    # second child: x -0.25..0.15, y -0.45..0.0
+    assert np.allclose(q[2].vertices["pos"][[0, 2], :2], [[-0.25, -0.45], [0.15, 0.0]], atol=1e-7)
+    s = scenes.ui_scene(root, [scenes.checker_texture(64, 4)], width=160, height=120)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    models = np.tile(ident, (3, 1))
+    r = orc.render(s, models, ident, ident, 160, 120, shading=2)
+    prim = r["prim"]
+    assert set(np.unique(prim)) == {0, 1, 2, 3, 0xFFFFFFFF}  # two rendered quads of two triangles; the main box is not drawn
+    # the first child covers pixels x in [46, 114), y in [51, 81) (NDC y grows downward on the target)
+    ys, xs = np.nonzero(prim < 2)
+    assert (xs.min(), xs.max(), ys.min(), ys.max()) == (46, 113, 51, 80)
+    assert (r["depth"][prim != 0xFFFFFFFF] == 0.0).all()  # z = 0: on the near plane, kept
+    # the second child is drawn later at the same depth: where they overlap the first one stays (Less)
+    both = (xs.min() <= 70) and prim[70, 60] in (0, 1)
+    assert both
