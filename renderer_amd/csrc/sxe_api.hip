@@ -462,7 +462,7 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
         SXE_HIP(c, fs.visible.reserve(std::max<size_t>(ho.size(), 1) * c->view_capacity));
         SXE_HIP(c, fs.pvm.reserve(std::max<size_t>(models.size(), 16) * c->view_capacity));
     }
-    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1) * c->view_capacity));
+    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1) * 4 * c->view_capacity)); // (a count per wave)
 
     c->n_meshes = (uint32_t)hm.size();
     c->n_objects = (uint32_t)ho.size();
@@ -753,7 +753,7 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
         return p;
     };
     w.counters = reinterpret_cast<FrameCounters *>(take(sizeof(FrameCounters)));
-    w.blk_count = reinterpret_cast<uint32_t *>(take(4 * std::max<size_t>(c->n_blocks, 1)));
+    w.blk_count = reinterpret_cast<uint32_t *>(take(16 * std::max<size_t>(c->n_blocks, 1)));
     w.tile_counters = reinterpret_cast<uint32_t *>(take(4 * 10 * ntc));
     w.tile_launch = reinterpret_cast<TileLaunch *>(take(sizeof(TileLaunch) * ntc));
     w.pvm = reinterpret_cast<float *>(take(64 * nobj));
@@ -806,7 +806,7 @@ int ensure_views(sxe_ctx *c, uint32_t views)
         SXE_HIP(c, fs.pvm.reserve(std::max<size_t>((size_t)c->n_objects * 16, 16) * views));
         SXE_HIP(c, fs.pv_views.reserve(16 * (size_t)views));
     }
-    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(c->n_blocks, 1) * views));
+    SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(c->n_blocks, 1) * 4 * views));
     SXE_HIP(c, c->tile_counters.reserve(9 * nt));
     SXE_HIP(c, c->tile_launch.reserve(nt));
     SXE_HIP(c, reserve_records(c));

@@ -308,34 +308,24 @@ struct Attr3 {
     float a0, a1, a2;
 };
 
-// Builds the records of one screen triangle that belongs in slot `rec`.  u, v are the per-corner
-// texture coordinates already multiplied by the corner's 1/w, cr/cg/cb the plain per-corner
-// colours, all in the original corner order; corners 1 and 2 are exchanged when the triangle was
-// reoriented.  The two records every triangle has are returned for the caller to store; the
-// optional ones (corners that do not fit the packed form, colour planes) are stored here.
-__device__ inline void make_records(const SetupArgs &a, uint32_t rec, const ScreenTri &s, uint32_t prim,
-                                    int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb, RastRec &r, ShadeRec &h)
+// Builds the two records every screen triangle has.  u, v are the per-corner texture coordinates
+// already multiplied by the corner's 1/w, in the original corner order; corners 1 and 2 are
+// exchanged when the triangle was reoriented.
+__device__ inline void make_records(const SetupArgs &a, const ScreenTri &s, uint32_t prim, int32_t texture, Attr3 u, Attr3 v,
+                                    RastRec &r, ShadeRec &h)
 {
     r.x0 = s.t.x0; r.y0 = s.t.y0;
     const int32_t dx1 = s.t.x1 - s.t.x0, dy1 = s.t.y1 - s.t.y0, dx2 = s.t.x2 - s.t.x0, dy2 = s.t.y2 - s.t.y0;
     const bool packed = narrow(s.t); // (then every offset is below 2^14 in magnitude)
     const uint32_t d1 = ((uint32_t)dx1 & 0xFFFFu) | ((uint32_t)dy1 << 16), d2 = ((uint32_t)dx2 & 0xFFFFu) | ((uint32_t)dy2 << 16);
-    r.d1 = packed ? d1 : kWideTri;
+    r.d1 = packed ? d1 : kWideTri; // (then the corners are in the slot's WideRec: wide_record())
     r.d2 = packed ? d2 : 0u;
-    if (!packed) {
-        WideRec w;
-        w.x1 = s.t.x1; w.y1 = s.t.y1; w.x2 = s.t.x2; w.y2 = s.t.y2;
-        a.wide[rec] = w;
-    }
     r.z0 = s.zn0; r.dz1 = s.zn1 - s.zn0; r.dz2 = s.zn2 - s.zn0;
     r.rA = s.rA;
     if (s.swapped) {
         float t;
         t = u.a1; u.a1 = u.a2; u.a2 = t;
         t = v.a1; v.a1 = v.a2; v.a2 = t;
-        t = cr.a1; cr.a1 = cr.a2; cr.a2 = t;
-        t = cg.a1; cg.a1 = cg.a2; cg.a2 = t;
-        t = cb.a1; cb.a1 = cb.a2; cb.a2 = t;
     }
     h.iw0 = s.rw0; h.diw1 = s.rw1 - s.rw0; h.diw2 = s.rw2 - s.rw0;
     if (a.shading != SXE_SHADE_VERTEX_COLOR) {
@@ -349,27 +339,48 @@ __device__ inline void make_records(const SetupArgs &a, uint32_t rec, const Scre
     h.prim = prim;
     h.fan_or_ra = __float_as_uint(s.rA);
     h.tex_fan = (uint32_t)texture & 0xFFFFFFu;
-    if (a.shading != SXE_SHADE_TEXTURE) {
-        const float r0 = cr.a0 * s.rw0, r1 = cr.a1 * s.rw1, r2 = cr.a2 * s.rw2;
-        const float g0 = cg.a0 * s.rw0, g1 = cg.a1 * s.rw1, g2 = cg.a2 * s.rw2;
-        const float b0 = cb.a0 * s.rw0, b1 = cb.a1 * s.rw1, b2 = cb.a2 * s.rw2;
-        ColorRec c;
-        c.rw0 = r0; c.drw1 = r1 - r0; c.drw2 = r2 - r0;
-        c.gw0 = g0; c.dgw1 = g1 - g0; c.dgw2 = g2 - g0;
-        c.bw0 = b0; c.dbw1 = b1 - b0; c.dbw2 = b2 - b0;
-        c.pad0 = c.pad1 = c.pad2 = 0.0f;
-        a.color[rec] = c;
-    }
 }
 
+// The corners of a triangle that does not fit the packed form.
+__device__ inline WideRec wide_record(const ScreenTri &s)
+{
+    WideRec w;
+    w.x1 = s.t.x1; w.y1 = s.t.y1; w.x2 = s.t.x2; w.y2 = s.t.y2;
+    return w;
+}
+
+// The colour planes (scenes shaded with vertex colours): cr/cg/cb are the plain per-corner colours
+// in the original corner order.
+__device__ inline ColorRec color_record(const ScreenTri &s, Attr3 cr, Attr3 cg, Attr3 cb)
+{
+    if (s.swapped) {
+        float t;
+        t = cr.a1; cr.a1 = cr.a2; cr.a2 = t;
+        t = cg.a1; cg.a1 = cg.a2; cg.a2 = t;
+        t = cb.a1; cb.a1 = cb.a2; cb.a2 = t;
+    }
+    const float r0 = cr.a0 * s.rw0, r1 = cr.a1 * s.rw1, r2 = cr.a2 * s.rw2;
+    const float g0 = cg.a0 * s.rw0, g1 = cg.a1 * s.rw1, g2 = cg.a2 * s.rw2;
+    const float b0 = cb.a0 * s.rw0, b1 = cb.a1 * s.rw1, b2 = cb.a2 * s.rw2;
+    ColorRec c;
+    c.rw0 = r0; c.drw1 = r1 - r0; c.drw2 = r2 - r0;
+    c.gw0 = g0; c.dgw1 = g1 - g0; c.dgw2 = g2 - g0;
+    c.bw0 = b0; c.dbw1 = b1 - b0; c.dbw2 = b2 - b0;
+    c.pad0 = c.pad1 = c.pad2 = 0.0f;
+    return c;
+}
+
+// All records of one screen triangle, straight to slot `rec`.
 __device__ inline void write_records(const SetupArgs &a, uint32_t rec, const ScreenTri &s, uint32_t prim,
                                      int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
 {
     RastRec r;
     ShadeRec h;
-    make_records(a, rec, s, prim, texture, u, v, cr, cg, cb, r, h);
+    make_records(a, s, prim, texture, u, v, r, h);
     a.rast[rec] = r;
     a.shade[rec] = h;
+    if (!narrow(s.t)) a.wide[rec] = wide_record(s);
+    if (a.shading != SXE_SHADE_TEXTURE) a.color[rec] = color_record(s, cr, cg, cb);
 }
 
 // One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
@@ -393,11 +404,16 @@ __device__ inline bool translucent_texture(const SetupArgs &a, int32_t texture)
 }
 
 // One thread per submitted triangle; a workgroup covers 256 consecutive triangles of one object
-// and owns 256 consecutive record slots, which it fills from the front in submission order.  That
-// order is what makes "first primitive wins a depth tie" (Comparison::Less,
-// src/renderer/drawer.rs:700) fall out of a (depth | slot) minimum.
+// and owns 256 consecutive record slots, 64 per wave, which each wave fills from the front in
+// submission order.  Slot numbers therefore order triangles as they were submitted, and that is
+// what makes "first primitive wins a depth tie" (Comparison::Less, src/renderer/drawer.rs:700) fall
+// out of a (depth | slot) minimum.  (Filling the 256 slots from the front across the waves packs
+// the records a little tighter, which the raster kernel gains 2 % from, but the waves then have
+// to meet once more before any of them knows its slots, which costs this kernel 4 %.)
+// TEX: texture shading only, so there are no colour planes to build or stage.
+template <bool TEX>
 struct SetupShared {
-    uint32_t wave_tot[kSetupThreads / 64];
+    static constexpr int kStageWords = TEX ? 5 : 8; // 16-byte words per record: raster 2, shading 3, colour 3
     union {
         // first the projected vertices of the work item's triangles: position, (z/w, 1/w), (u/w, v/w), flags
         struct {
@@ -406,14 +422,14 @@ struct SetupShared {
             float2 uv[kVtxCache];
             uint32_t mask[kVtxCache];
         } vtx;
-        // then the finished records in slot order, on their way to memory
-        uint4 stage[kSetupThreads * 5];
+        // then the finished records of every wave, in its own order, on their way to memory
+        uint4 stage[kSetupThreads * kStageWords];
     };
 };
 
-__device__ inline void setup_block(const SetupArgs &a, const uint32_t block, const uint32_t view, SetupShared &sh)
+template <bool TEX>
+__device__ inline void setup_block(const SetupArgs &a, const uint32_t block, const uint32_t view, SetupShared<TEX> &sh)
 {
-    uint32_t *s_wave_tot = sh.wave_tot;
     int2 *s_xy = sh.vtx.xy;
     float2 *s_zr = sh.vtx.zr, *s_uv = sh.vtx.uv;
     uint32_t *s_mask = sh.vtx.mask;
@@ -426,12 +442,21 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
     const bool cached = bd.vtx_n <= (uint32_t)kVtxCache;
     const uint32_t vblock = view * a.n_blocks + block; // work item number over all views: names its record slots
     const size_t vobject = (size_t)view * a.n_objects + bd.object;
-    if (!a.visible[vobject]) {
-        if (tid == 0) a.blk_count[vblock] = 0;
+    uint32_t *wave_count = a.blk_count + (size_t)vblock * (kSetupThreads / 64); // survivors of each wave of this work item
+    // (the flag's aligned word: a uniform word is a scalar load, a byte is a vector load)
+    const uint32_t visible_word = reinterpret_cast<const uint32_t *>(a.visible)[vobject >> 2];
+    if (!((visible_word >> (8u * ((uint32_t)vobject & 3u))) & 0xFFu)) {
+        if (tid < kSetupThreads / 64) wave_count[tid] = 0;
         return;
     }
     const float *pvm = a.pvm + 16 * vobject;
     const bool translucent = translucent_texture(a, bd.texture); // (the same for the whole work item)
+    // (asked for before the vertex phase: the reply is not on the critical path then)
+    uint32_t i0 = 0, i1 = 0, i2 = 0;
+    if (valid) {
+        const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
+        i0 = ip[0]; i1 = ip[1]; i2 = ip[2];
+    }
     if (cached) {
         for (uint32_t i = (uint32_t)tid; i < bd.vtx_n; i += kSetupThreads) {
             const sxe_vertex &w = a.vertices[bd.vtx_base + bd.vtx_lo + i];
@@ -444,20 +469,16 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
         __syncthreads();
     }
     if ((a.debug & kDebugSkipRaster) && (a.debug & kDebugSkipResolve)) { // development: stop after the vertex phase
-        if (tid == 0) a.blk_count[vblock] = 0;
+        if (tid < kSetupThreads / 64) wave_count[tid] = 0;
         return;
     }
 
-    enum { CULLED = 0, FAST = 1, CLIP = 2 };
-    int state = CULLED;
-    ScreenTri st;
-    st.px0 = st.px1 = st.py0 = st.py1 = 0;
+    // the triangle's corners; all three outside one plane of the view volume -> nothing visible;
+    // one outside a guard-band, near or far plane -> the clipper's
+    bool candidate = false, clip = false;
+    PVert v0 = {0, 0, 0.0f, 0.0f, 0u}, v1 = v0, v2 = v0;
     Attr3 uw = {0, 0, 0}, vw = {0, 0, 0};
-
     if (valid) {
-        const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
-        const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
-        PVert v0, v1, v2;
         if (cached) {
             const uint32_t k0 = i0 - bd.vtx_lo, k1 = i1 - bd.vtx_lo, k2 = i2 - bd.vtx_lo;
             const int2 q0 = s_xy[k0], q1 = s_xy[k1], q2 = s_xy[k2];
@@ -476,172 +497,154 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
             uw = {w0.uv[0] * v0.rw, w1.uv[0] * v1.rw, w2.uv[0] * v2.rw};
             vw = {w0.uv[1] * v0.rw, w1.uv[1] * v1.rw, w2.uv[1] * v2.rw};
         }
-        // all three corners outside one plane of the view volume -> nothing visible
         const bool rej = (v0.mask & v1.mask & v2.mask & kOutVolume) != 0;
-        if (!rej) {
-            const bool inside = ((v0.mask | v1.mask | v2.mask) & kOutGuard) == 0;
-            if (inside) {
-                if (setup_screen_tri(v0, v1, v2, a.g, st)) {
-                    state = FAST;
-                    // a triangle whose box holds a few pixels and contains none of their samples draws nothing
-                    const int32_t bw = st.px1 - st.px0 + 1, bh = st.py1 - st.py0 + 1;
-                    if (bw * bh <= 4 && narrow(st.t) && !covers_any(st.t, st.px0, st.px1, st.py0, st.py1)) state = CULLED;
-                }
-            } else {
-                state = CLIP; // crosses the near, far or a guard-band plane: k_clip cuts it
-            }
-        }
+        const bool inside = ((v0.mask | v1.mask | v2.mask) & kOutGuard) == 0;
+        candidate = !rej && inside;
+        clip = !rej && !inside;
     }
-
-    // rank of every survivor inside the workgroup
-    const unsigned long long alive = __ballot(state != CULLED);
-    const uint32_t wave_rank = (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave_tot[wave] = (uint32_t)__popcll(alive);
+    // The projected vertices have been read: from here on the same LDS stages the finished
+    // records.  A wave keeps to itself after this barrier: it has its own slots and its own piece
+    // of the staging area.
     __syncthreads();
-    uint32_t wave_base = 0, total = 0;
-    for (int w = 0; w < kSetupThreads / 64; ++w) {
-        const uint32_t v = s_wave_tot[w];
-        if (w < wave) wave_base += v;
-        total += v;
-    }
-    if (tid == 0) a.blk_count[vblock] = total;
-    const uint32_t local = wave_base + wave_rank;
-    const uint32_t slot0 = vblock * kSetupThreads, slot = slot0 + local;
-    const uint32_t tile0 = view * a.g.n_tiles; // the view's first tile in the per-tile tables and the bins
+    constexpr int kStageWords = SetupShared<TEX>::kStageWords;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint4 *sr = sh.stage + wave * (kStageWords * 64), *ss = sr + 2 * 64, *sc = sr + 5 * 64; // raster, shading, colour records
+    const unsigned long long clip_mask = __ballot(clip);
+    const uint32_t wslot0 = (vblock * (kSetupThreads / 64) + (uint32_t)wave) * 64u; // the wave's first slot
     const uint32_t prim = bd.prim_base + t;
+    const uint32_t tile0 = view * a.g.n_tiles; // the view's first tile in the per-tile tables and the bins
 
-    // Bin entries of triangles that lie in one tile are reserved here, one atomic per (tile, size
-    // class) group of the wave; the reply is needed only when the keys are staged further down.
-    const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
-    const bool single = (state == FAST) && tx0 == st.px1 / kTile && ty0 == st.py1 / kTile;
-    const uint32_t part = size_class((uint32_t)((st.px1 - st.px0 + 1) * (st.py1 - st.py0 + 1)), narrow(st.t));
-    // A triangle that touches up to four tiles reserves an entry in each of those bins as well;
-    // larger ones are only counted and take their entries in k_finish.
-    const uint32_t cols_m1 = (uint32_t)(st.px1 / kTile - tx0), rows_m1 = (uint32_t)(st.py1 / kTile - ty0);
-    const uint32_t n_touched = (cols_m1 + 1u) * (rows_m1 + 1u);
-    const bool few = (state == FAST) && !single && n_touched <= 4u;
-    // Entry j of a lane goes to the counter 4 * tile + size class.  The
-    // lanes of the wave whose entry j names the same counter share one atomic: neighbouring
-    // triangles fall into the same tiles, and a reservation that many lanes make on one counter
-    // one after the other is slow to come back.
-    uint32_t raw4[4] = {0, 0, 0, 0};   // the group's reservation, valid in its leader lane
-    uint32_t who4[4] = {0, 0, 0, 0};   // leader lane | rank inside the group << 8
-    {
-        const uint32_t first = tile0 + (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
-        uint32_t cx = 0, cy = 0;
+    bool fast = false;
+    if (candidate) {
+        ScreenTri st;
+        if (setup_screen_tri(v0, v1, v2, a.g, st)) {
+            // a triangle whose box holds a few pixels and contains none of their samples draws nothing
+            const int32_t bw = st.px1 - st.px0 + 1, bh = st.py1 - st.py0 + 1;
+            const bool is_narrow = narrow(st.t);
+            if (!(bw * bh <= 4 && is_narrow && !covers_any(st.t, st.px0, st.px1, st.py0, st.py1))) {
+                fast = true;
+                // Rank among the wave's survivors (clipped triangles keep a slot too): the lanes that
+                // are here are exactly the ones that draw without the clipper.
+                const unsigned long long fast_mask = __ballot(true);
+                const uint32_t rank = (uint32_t)__popcll((fast_mask | clip_mask) & below);
+                const uint32_t slot = wslot0 + rank;
+
+                // Bin entries.  A triangle that lies in one tile, or touches up to four, reserves an
+                // entry in the region of its size class in each of those bins, one atomic per (tile,
+                // size class) group of the wave: neighbouring triangles fall into the same tiles, and
+                // a reservation that many lanes make on one counter one after the other is slow to
+                // come back (grouping only lanes that follow one another, which needs no loop over the
+                // distinct counters, made a third more atomics and the kernel a quarter slower).  The
+                // reply is needed only after the records have been built.
+                const int32_t tx0 = st.px0 / kTile, ty0 = st.py0 / kTile;
+                const uint32_t cols_m1 = (uint32_t)(st.px1 / kTile - tx0), rows_m1 = (uint32_t)(st.py1 / kTile - ty0);
+                const uint32_t n_touched = (cols_m1 + 1u) * (rows_m1 + 1u);
+                const bool few = n_touched <= 4u; // (one tile included)
+                const uint32_t part = size_class((uint32_t)(bw * bh), is_narrow);
+                const uint32_t first = tile0 + (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
+                uint32_t raw4[4] = {0, 0, 0, 0};   // the reservation of the lane's group, valid in its leader lane
+                uint32_t who4[4] = {0, 0, 0, 0};   // leader lane | rank inside the group << 8
+                {
+                    uint32_t cx = 0, cy = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool has = (j == 0 && single) || (few && (uint32_t)j < n_touched);
-            const uint32_t counter = 4u * (first + cy * a.g.tiles_x + cx) + part;
-            uint32_t count_j = 0;
-            who4[j] = (uint32_t)lane;
-            unsigned long long pending = __ballot(has);
-            while (pending) {
-                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
-                const uint32_t lk = __builtin_amdgcn_readlane(counter, leader);
-                const bool mine = has && counter == lk;
-                const unsigned long long same = __ballot(mine);
-                if (mine) {
-                    who4[j] = (uint32_t)leader | ((uint32_t)__popcll(same & ((1ull << lane) - 1ull)) << 8);
-                    count_j = (uint32_t)__popcll(same);
+                    for (int j = 0; j < 4; ++j) {
+                        const bool has = few && (uint32_t)j < n_touched;
+                        const uint32_t counter = 4u * (first + cy * a.g.tiles_x + cx) + part;
+                        who4[j] = (uint32_t)lane;
+                        uint32_t count_j = 0;
+                        unsigned long long pending = __ballot(has);
+                        while (pending) {
+                            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+                            const uint32_t lk = __builtin_amdgcn_readlane(counter, leader);
+                            const bool mine = has && counter == lk;
+                            const unsigned long long same = __ballot(mine);
+                            if (mine) {
+                                who4[j] = (uint32_t)leader | ((uint32_t)__popcll(same & below) << 8);
+                                count_j = (uint32_t)__popcll(same);
+                            }
+                            pending &= ~same;
+                        }
+                        if (has && (uint32_t)lane == (who4[j] & 255u)) {
+                            raw4[j] = atomicAdd(&a.tiles[counter >> 2].cnt[counter & 3u], count_j);
+                            if (translucent) atomicOr(&a.tiles[counter >> 2].flags, kTileBlend);
+                        }
+                        if (++cx > cols_m1) { cx = 0; ++cy; }
+                    }
                 }
-                pending &= ~same;
+                {
+                    // Triangles over more than four tiles are only counted here; their slots go on a
+                    // list that k_finish spreads evenly over waves of its own (one list position per
+                    // wave of this kernel would leave a wave full of such triangles with all of their
+                    // entries to file).
+                    const bool walker = !few;
+                    if (walker) count_box(a, view, st, translucent);
+                    const unsigned long long wm = __ballot(walker);
+                    if (wm) {
+                        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
+                        uint32_t at = 0;
+                        if (lane == leader) at = atomicAdd(&a.counters->walk_count, (uint32_t)__popcll(wm));
+                        at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+                        if (walker) a.walk_list[at + (uint32_t)__popcll(wm & below)] = slot;
+                    }
+                }
+
+                // The records go to memory through LDS: a lane storing its own 32- and 48-byte
+                // records would send the L2 one 16-byte request per lane and instruction; laid out
+                // in slot order first, the wave stores them as whole cache lines.
+                RastRec r;
+                ShadeRec h;
+                make_records(a, st, prim, bd.texture, uw, vw, r, h);
+                sr[2 * rank] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
+                sr[2 * rank + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), __float_as_uint(r.rA));
+                ss[3 * rank] = make_uint4(__float_as_uint(h.iw0), __float_as_uint(h.diw1), __float_as_uint(h.diw2), __float_as_uint(h.uw0));
+                ss[3 * rank + 1] = make_uint4(__float_as_uint(h.duw1), __float_as_uint(h.duw2), __float_as_uint(h.vw0), __float_as_uint(h.dvw1));
+                ss[3 * rank + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_or_ra, h.tex_fan);
+                if (!TEX) {
+                    // (the indices are read again rather than kept in registers all the way down here)
+                    const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
+                    const sxe_vertex &w0 = a.vertices[bd.vtx_base + ip[0]], &w1 = a.vertices[bd.vtx_base + ip[1]],
+                                     &w2 = a.vertices[bd.vtx_base + ip[2]];
+                    const ColorRec c = color_record(st, {w0.color[0], w1.color[0], w2.color[0]}, {w0.color[1], w1.color[1], w2.color[1]},
+                                                    {w0.color[2], w1.color[2], w2.color[2]});
+                    sc[3 * rank] = make_uint4(__float_as_uint(c.rw0), __float_as_uint(c.drw1), __float_as_uint(c.drw2), __float_as_uint(c.gw0));
+                    sc[3 * rank + 1] = make_uint4(__float_as_uint(c.dgw1), __float_as_uint(c.dgw2), __float_as_uint(c.bw0), __float_as_uint(c.dbw1));
+                    sc[3 * rank + 2] = make_uint4(__float_as_uint(c.dbw2), 0u, 0u, 0u);
+                }
+                if (!is_narrow) a.wide[slot] = wide_record(st);
+
+                // File the triangle: its slot number goes to the reserved position of the size
+                // class's region in the bin of every tile it touches.
+                {
+                    const uint32_t cap = pick_region(a.bl.cap, part), off = pick_region(a.bl.off, part);
+                    uint32_t cx = 0, cy = 0;
+                    bool over = false; // (then the frame is drawn again with larger regions)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool has = few && (uint32_t)j < n_touched;
+                        const uint32_t at = (uint32_t)__shfl((int)raw4[j], (int)(who4[j] & 255u)) + (who4[j] >> 8);
+                        if (has && at < cap) a.bins[(first + cy * a.g.tiles_x + cx) * a.bl.stride + off + at] = slot;
+                        over |= has && at >= cap;
+                        if (++cx > cols_m1) { cx = 0; ++cy; }
+                    }
+                    if (over) atomicOr(&a.counters->overflow, kOverflowBins);
+                }
             }
-            if (has && (uint32_t)lane == (who4[j] & 255u)) {
-                raw4[j] = atomicAdd(&a.tiles[counter >> 2].cnt[counter & 3u], count_j);
-                if (translucent) atomicOr(&a.tiles[counter >> 2].flags, kTileBlend);
-            }
-            if (++cx > cols_m1) { cx = 0; ++cy; }
-        }
-    }
-    {
-        // Triangles over more than four tiles are only counted here; their slots go on a list that
-        // k_finish spreads evenly over waves of its own (one list position per wave of this kernel
-        // would leave a wave full of such triangles with all of their entries to file).
-        const bool walker = state == FAST && !single && !few;
-        if (walker) count_box(a, view, st, translucent);
-        const unsigned long long wm = __ballot(walker);
-        if (wm) {
-            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)wm) - 1);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&a.counters->walk_count, (uint32_t)__popcll(wm));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (walker) a.walk_list[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = slot;
         }
     }
 
-    // The records go to memory through LDS: a lane storing its own 32- and 48-byte records would
-    // send the L2 one 16-byte request per lane and instruction; laid out in slot order first, the
-    // workgroup stores them as whole cache lines.
-    RastRec r;
-    ShadeRec h;
-    r.x0 = kNoRaster; r.y0 = 0; r.d1 = 0; r.d2 = 0; r.z0 = r.dz1 = r.dz2 = r.rA = 0.0f;
-    h.iw0 = h.diw1 = h.diw2 = h.uw0 = h.duw1 = h.duw2 = h.vw0 = h.dvw1 = h.dvw2 = 0.0f;
-    h.prim = prim; h.fan_or_ra = 0; h.tex_fan = 0; // k_clip fills in the slot of a clipped triangle
-    if (state == FAST) {
-        Attr3 cr = {0, 0, 0}, cg = {0, 0, 0}, cb = {0, 0, 0};
-        if (a.shading != SXE_SHADE_TEXTURE) {
-            // (the indices are read again rather than kept in registers all the way down here)
-            const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
-            const sxe_vertex &w0 = a.vertices[bd.vtx_base + ip[0]], &w1 = a.vertices[bd.vtx_base + ip[1]],
-                             &w2 = a.vertices[bd.vtx_base + ip[2]];
-            cr = {w0.color[0], w1.color[0], w2.color[0]};
-            cg = {w0.color[1], w1.color[1], w2.color[1]};
-            cb = {w0.color[2], w1.color[2], w2.color[2]};
-        }
-        make_records(a, slot, st, prim, bd.texture, uw, vw, cr, cg, cb, r, h);
-    }
-    // File the triangle: its slot number goes to the reserved position of the size class's region
-    // in the bin of every tile it touches (up to four; larger ones are on the walk list).
-    {
-        const uint32_t first = tile0 + (uint32_t)(ty0 - (int32_t)a.g.tile_row0) * a.g.tiles_x + (uint32_t)tx0;
-        const uint32_t cap = pick_region(a.bl.cap, part), off = pick_region(a.bl.off, part);
-        bool over = false;
-        uint32_t cx = 0, cy = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool has = (j == 0 && single) || (few && (uint32_t)j < n_touched);
-            const uint32_t at = (uint32_t)__shfl((int)raw4[j], (int)(who4[j] & 255u)) + (who4[j] >> 8);
-            if (has) {
-                if (at < cap)
-                    a.bins[(first + cy * a.g.tiles_x + cx) * a.bl.stride + off + at] = slot;
-                else
-                    over = true;
-            }
-            if (++cx > cols_m1) { cx = 0; ++cy; }
-        }
-        if (__ballot(over) && lane == 0) atomicOr(&a.counters->overflow, kOverflowBins);
-    }
-    // (the rank barrier above came after the last read of the vertex arrays, which `stage` overlays)
-    if (state != CULLED) {
-        uint4 *sr = sh.stage, *ss = sh.stage + 2 * kSetupThreads; // raster records, then shading records
-        sr[2 * local] = make_uint4((uint32_t)r.x0, (uint32_t)r.y0, r.d1, r.d2);
-        sr[2 * local + 1] = make_uint4(__float_as_uint(r.z0), __float_as_uint(r.dz1), __float_as_uint(r.dz2), __float_as_uint(r.rA));
-        ss[3 * local] = make_uint4(__float_as_uint(h.iw0), __float_as_uint(h.diw1), __float_as_uint(h.diw2), __float_as_uint(h.uw0));
-        ss[3 * local + 1] = make_uint4(__float_as_uint(h.duw1), __float_as_uint(h.duw2), __float_as_uint(h.vw0), __float_as_uint(h.dvw1));
-        ss[3 * local + 2] = make_uint4(__float_as_uint(h.dvw2), h.prim, h.fan_or_ra, h.tex_fan);
-    }
-    __syncthreads();
-    {
-        // (total <= 256: at most two and three 16-byte pieces per thread)
-        uint4 *dst = reinterpret_cast<uint4 *>(a.rast + slot0);
-#pragma unroll
-        for (uint32_t k = 0; k < 2u; ++k) {
-            const uint32_t c = (uint32_t)tid + k * kSetupThreads;
-            if (c < 2u * total) dst[c] = sh.stage[c];
-        }
-        dst = reinterpret_cast<uint4 *>(a.shade + slot0);
-        const uint4 *ss = sh.stage + 2 * kSetupThreads;
-#pragma unroll
-        for (uint32_t k = 0; k < 3u; ++k) {
-            const uint32_t c = (uint32_t)tid + k * kSetupThreads;
-            if (c < 3u * total) dst[c] = ss[c];
-        }
-    }
-
+    const unsigned long long alive = __ballot(fast || clip);
+    const uint32_t n_alive = (uint32_t)__popcll(alive);
+    if (lane == 0) wave_count[wave] = n_alive;
     // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
-    // order) and are queued for k_clip ----
-    if (state == CLIP) {
+    // order) and are queued for k_clip, which fills the slot in ----
+    if (clip) {
+        const uint32_t rank = (uint32_t)__popcll(alive & below), slot = wslot0 + rank;
+        sr[2 * rank] = make_uint4((uint32_t)kNoRaster, 0u, 0u, 0u);
+        sr[2 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
+        ss[3 * rank] = make_uint4(0u, 0u, 0u, 0u);
+        ss[3 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
+        ss[3 * rank + 2] = make_uint4(0u, prim, 0u, 0u);
+        if (!TEX) sc[3 * rank] = sc[3 * rank + 1] = sc[3 * rank + 2] = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t at = atomicAdd(&a.counters->clip_count, 1u);
         if (a.clip_off) {
             atomicOr(&a.counters->overflow, kOverflowNoClip);
@@ -653,19 +656,46 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
             atomicOr(&a.counters->overflow, kOverflowClip);
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    // the wave's staged records to its slots (its own LDS writes are done when it reads them back)
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(a.rast + wslot0);
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint32_t c = (uint32_t)lane + k * 64u;
+            if (c < 2u * n_alive) dst[c] = sr[c];
+        }
+        dst = reinterpret_cast<uint4 *>(a.shade + wslot0);
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const uint32_t c = (uint32_t)lane + k * 64u;
+            if (c < 3u * n_alive) dst[c] = ss[c];
+        }
+        if (!TEX) {
+            dst = reinterpret_cast<uint4 *>(a.color + wslot0);
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t c = (uint32_t)lane + k * 64u;
+                if (c < 3u * n_alive) dst[c] = sc[c];
+            }
+        }
+    }
 }
 
 // (six resident waves per SIMD matter more to this kernel than the last few registers)
 // DEV: built with the development switches of SetupArgs::debug; the ordinary build has none of
 // their tests in its code.
-template <bool DEV>
+// TEX: texture shading only (the usual case), so the colour planes, the loads for them and their
+// share of the staging area drop out.
+template <bool DEV, bool TEX>
 __global__ __launch_bounds__(kSetupThreads) void k_setup(SetupArgs a)
 {
     if (!DEV) a.debug = 0u;
+    if (TEX) a.shading = SXE_SHADE_TEXTURE;
     // one work item per workgroup (several in a loop measured slower, and a loop keeps per-thread
     // addresses alive across it, which this kernel has no registers for)
-    __shared__ SetupShared sh;
-    setup_block(a, blockIdx.x, blockIdx.y, sh); // grid: x over the work items of a view, y over the views
+    __shared__ SetupShared<TEX> sh;
+    setup_block<TEX>(a, blockIdx.x, blockIdx.y, sh); // grid: x over the work items of a view, y over the views
 }
 
 // One thread per queued triangle: Sutherland-Hodgman, then the fan of the clipped polygon goes to
@@ -888,7 +918,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
     const uint32_t n_tiles = total_tiles(a.g);       // of all views
     const uint32_t last_tile = max(n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
     const uint32_t chunks = max((n_tiles + kOrderChunk - 1u) / kOrderChunk, 1u);
-    const uint32_t n_blocks = a.n_blocks * a.g.views;
+    const uint32_t n_blocks = a.n_blocks * a.g.views * (kSetupThreads / 64); // (one count per wave of a setup work item)
     if (blockIdx.x == 0) {
         // four counts per load, sixteen loads in flight per thread
         uint32_t sum = 0;
@@ -1042,10 +1072,15 @@ hipError_t launch_vertex(const float *px, const float *py, const float *pz, cons
 hipError_t launch_setup(const SetupArgs &a, hipStream_t s)
 {
     if (a.n_blocks == 0) return hipSuccess;
-    if (a.debug)
-        hipLaunchKernelGGL(k_setup<true>, dim3(a.n_blocks, a.g.views), dim3(kSetupThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_setup<false>, dim3(a.n_blocks, a.g.views), dim3(kSetupThreads), 0, s, a);
+    const dim3 grid(a.n_blocks, a.g.views), block(kSetupThreads);
+    const bool tex = a.shading == SXE_SHADE_TEXTURE;
+    if (a.debug) {
+        if (tex) hipLaunchKernelGGL((k_setup<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_setup<true, false>), grid, block, 0, s, a);
+    } else {
+        if (tex) hipLaunchKernelGGL((k_setup<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_setup<false, false>), grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ struct SetupArgs {
     uint32_t shading;
     uint32_t debug;            // kDebug* switches (development only)
     FrameGeom g;
-    uint32_t *blk_count;       // survivors per workgroup
+    uint32_t *blk_count;       // survivors per wave of every work item (four counts each)
     TileCtr *tiles;
     uint32_t *bins;
     BinLayout bl;
