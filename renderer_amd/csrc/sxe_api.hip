@@ -1094,7 +1094,7 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
     }
     rc = sxe_sync(c); // frames in flight still sample the old table
     if (rc) return rc;
-    SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16)));
+    SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16) + 4)); // (a spare texel: the tile kernels load texels in pairs)
     SXE_HIP(c, c->textab.reserve(std::max<size_t>(n, 1)));
     for (uint32_t t = 0; t < n; ++t)
         SXE_HIP(c, hipMemcpy(c->texels.p + 4 * (size_t)tab[t].offset, textures[t].rgba,

@@ -136,8 +136,15 @@ __device__ inline uint32_t unorm8_encode(float a)
 // (standard.frag:12; sampler at src/renderer/drawer.rs:231; format at src/renderer/types.rs:186),
 // split into texel addressing and filtering so that the four fetches of several pixels overlap.
 struct TexelQuad {
-    uint32_t i00, i10, i01, i11; // texel indices into the pooled texel buffer
+    uint32_t p0, p1; // texel indices (into the pooled texel buffer) of the pair of neighbours to load from either row
+    bool hi0, hi1;   // the quad's left / right texel is the second of its row's pair
     float ax, ay;
+};
+// The two texels of a row of the quad are neighbours in memory unless the clamp made them one and
+// the same, and then a pair that contains it is loaded: two 8-byte loads per pixel instead of four
+// 4-byte ones.  (The texel pool ends with a spare texel for one-texel-wide rows.)
+struct __attribute__((packed, aligned(4))) TexelPair {
+    uint32_t first, second;
 };
 
 __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
@@ -158,10 +165,11 @@ __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
     // rows and widths are at most 16384 (checked when the textures are set): the full-rate 24-bit
     // multiply gives the same product as the general one, which costs four times as much
     const uint32_t row0 = t.offset + __umul24((uint32_t)iy0, t.width), row1 = t.offset + __umul24((uint32_t)iy1, t.width);
-    q.i00 = row0 + (uint32_t)ix0;
-    q.i10 = row0 + (uint32_t)ix1;
-    q.i01 = row1 + (uint32_t)ix0;
-    q.i11 = row1 + (uint32_t)ix1;
+    const int base = min(ix0, max(mw - 1, 0));
+    q.p0 = row0 + (uint32_t)base;
+    q.p1 = row1 + (uint32_t)base;
+    q.hi0 = ix0 != base;
+    q.hi1 = ix1 != base;
     return q;
 }
 
@@ -421,7 +429,9 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
         const TexDev td = MANYTEX ? a.textures[ti] : s_tex[ti];
         const TexelQuad tq = texel_quad(td, u, v);
         m.ax = tq.ax; m.ay = tq.ay;
-        m.t00 = texels[tq.i00]; m.t10 = texels[tq.i10]; m.t01 = texels[tq.i01]; m.t11 = texels[tq.i11];
+        const TexelPair a0 = *reinterpret_cast<const TexelPair *>(texels + tq.p0), a1 = *reinterpret_cast<const TexelPair *>(texels + tq.p1);
+        m.t00 = tq.hi0 ? a0.second : a0.first; m.t10 = tq.hi1 ? a0.second : a0.first;
+        m.t01 = tq.hi0 ? a1.second : a1.first; m.t11 = tq.hi1 ? a1.second : a1.first;
     }
     return m;
 }
@@ -873,7 +883,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
                 const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
                 const TexDev td = a.textures[h.tex_fan & 0xFFFFFFu];
                 const TexelQuad tq = texel_quad(td, u, v);
-                filter_quad_rgba(s_dec, s_un, texels[tq.i00], texels[tq.i10], texels[tq.i01], texels[tq.i11], tq.ax, tq.ay, src);
+                const TexelPair a0 = *reinterpret_cast<const TexelPair *>(texels + tq.p0), a1 = *reinterpret_cast<const TexelPair *>(texels + tq.p1);
+                filter_quad_rgba(s_dec, s_un, tq.hi0 ? a0.second : a0.first, tq.hi1 ? a0.second : a0.first,
+                                 tq.hi0 ? a1.second : a1.first, tq.hi1 ? a1.second : a1.first, tq.ax, tq.ay, src);
                 if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
                     const ColorRec c = a.color[rec];
                     src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
