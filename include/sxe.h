@@ -140,7 +140,11 @@ const char *sxe_version(void);
  * pixel.  A texture with any other alpha makes the screen tiles its triangles touch take an ordered
  * path that depth-tests and blends every fragment in submission order (BlendState::ALPHA,
  * src/renderer/drawer.rs:660-663): exact, much slower, and limited to 4096 bin entries per such
- * 32x32 tile (SXE_E_CAPACITY from sxe_sync beyond). */
+ * 32x32 tile (SXE_E_CAPACITY from sxe_sync beyond).
+ * On the device a texture is kept as a table of its (width + 1) x (height + 1) bilinear footprints
+ * (the four texels of every possible sample, clamp to edge applied; 16 bytes each) next to the
+ * texels as given: about 20 bytes of device memory per texel; all tables together hold fewer than
+ * 2^32 entries (SXE_E_CAPACITY). */
 int sxe_set_textures(sxe_ctx *ctx, const sxe_texture_desc *textures, uint32_t n);
 /* One mesh per drawable, drawn once, as the reference stores them (src/renderer/drawer.rs:173-193). */
 int sxe_update_drawables(sxe_ctx *ctx, const sxe_drawable *drawables, uint32_t n);

@@ -154,7 +154,8 @@ struct sxe_ctx {
     DevBuf<float> models;
     DevBuf<sxe_transform> transforms;
     bool have_transforms = false;
-    DevBuf<uint8_t> texels;
+    DevBuf<uint8_t> texels;    // the textures as they were given, back to back (source of the footprint tables)
+    DevBuf<uint4> footprints;  // (width + 1) x (height + 1) bilinear footprints per texture, back to back
     DevBuf<TexDev> textab;
     Mat4 view, proj, pv;
 
@@ -675,7 +676,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     ra.n_slots = fs.views * c->n_blocks * kSetupThreads;
     ra.image_stride = (size_t)c->cfg.width * c->cfg.height;
     ra.counters = w.counters;
-    ra.texels = c->texels.p;
+    ra.footprints = c->footprints.p;
     ra.textures = c->textab.p;
     ra.n_textures = c->n_textures;
     ra.out_color = img.color;
@@ -1030,6 +1031,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
+    if ((e = c->footprints.reserve(1)) != hipSuccess) return bail("hipMalloc(footprints)", e);
     if ((e = c->textab.reserve(1)) != hipSuccess) return bail("hipMalloc(texture table)", e);
     *out = c;
     return SXE_OK;
@@ -1042,7 +1044,7 @@ void sxe_destroy(sxe_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->vertices.release(); c->pos_x.release(); c->pos_y.release(); c->pos_z.release();
     c->indices.release(); c->meshes.release(); c->insts.release(); c->blocks.release(); c->vblocks.release();
-    c->models.release(); c->transforms.release(); c->texels.release(); c->textab.release();
+    c->models.release(); c->transforms.release(); c->texels.release(); c->footprints.release(); c->textab.release();
     c->blk_count.release(); c->wide.release(); c->clip_list.release(); c->object_mesh.release(); c->tile_counters.release(); c->walk_list.release(); c->fan_order.release(); c->tile_launch.release();
     c->bins.release(); c->rast.release(); c->shade.release(); c->color.release(); c->counters.release();
     c->clip.release(); c->tile_times.release();
@@ -1072,7 +1074,8 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
     if (n && !textures) return fail(c, SXE_E_INVALID, "null texture table");
     if (n > 65536) return fail(c, SXE_E_CAPACITY, "at most 65536 textures");
     std::vector<TexDev> tab(n);
-    size_t total = 0;
+    std::vector<size_t> texel_at(n);
+    size_t total = 0, entries = 0;
     bool any_translucent = false;
     for (uint32_t t = 0; t < n; ++t) {
         const sxe_texture_desc &d = textures[t];
@@ -1085,21 +1088,29 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
         bool translucent = false;
         for (size_t i = 0; i < px && !translucent; ++i) translucent = d.rgba[4 * i + 3] != 255;
         any_translucent = any_translucent || translucent;
-        tab[t].offset = (uint32_t)total;
+        texel_at[t] = total;
+        tab[t].offset = (uint32_t)entries;
         tab[t].width = d.width;
         tab[t].height = d.height;
         tab[t].flags = translucent ? kTexTranslucent : 0u;
         total += px;
-        if (total > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
+        entries += ((size_t)d.width + 1) * ((size_t)d.height + 1);
+        if (entries > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
     }
     rc = sxe_sync(c); // frames in flight still sample the old table
     if (rc) return rc;
-    SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16) + 4)); // (a spare texel: the tile kernels load texels in pairs)
+    SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16)));
+    SXE_HIP(c, c->footprints.reserve(std::max<size_t>(entries, 1)));
     SXE_HIP(c, c->textab.reserve(std::max<size_t>(n, 1)));
-    for (uint32_t t = 0; t < n; ++t)
-        SXE_HIP(c, hipMemcpy(c->texels.p + 4 * (size_t)tab[t].offset, textures[t].rgba,
-                             4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice));
-    if (n) SXE_HIP(c, hipMemcpy(c->textab.p, tab.data(), n * sizeof(TexDev), hipMemcpyHostToDevice));
+    // The tile kernels sample tables of ready-made bilinear footprints (16 bytes per texel), built
+    // here on the device from the texels as given.
+    for (uint32_t t = 0; t < n; ++t) {
+        uint8_t *texels = c->texels.p + 4 * texel_at[t];
+        SXE_HIP(c, hipMemcpyAsync(texels, textures[t].rgba, 4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice, c->stream));
+        SXE_HIP(c, launch_texture_footprints(texels, tab[t].width, tab[t].height, c->footprints.p + tab[t].offset, c->stream));
+    }
+    if (n) SXE_HIP(c, hipMemcpyAsync(c->textab.p, tab.data(), n * sizeof(TexDev), hipMemcpyHostToDevice, c->stream));
+    SXE_HIP(c, hipStreamSynchronize(c->stream)); // (the caller's pixels and `tab` are only borrowed)
     c->n_textures = n;
     c->blend_scene = any_translucent;
     // The scene's texture indices were checked against the table of its upload.  A table that no

@@ -71,14 +71,14 @@ struct VBlockDesc { // work item of the vertex kernel: up to 1024 consecutive ve
 };
 
 struct TexDev {
-    uint32_t offset; // first texel in the pooled texel buffer
+    uint32_t offset; // first entry of the texture's table in the pooled footprint tables
     uint32_t width, height;
     uint32_t flags;  // kTexTranslucent
 };
 constexpr uint32_t kTexTranslucent = 1u; // some texel has alpha below 255: fragments must be blended in submission order
 
-// Record storage.  Setup workgroup b owns slots [256 b, 256 b + 256) and fills them from the front
-// in submission order, so a slot number orders triangles as they were submitted.  Triangles cut by
+// Record storage.  Setup workgroup b owns slots [256 b, 256 b + 256), 64 per wave, and every wave
+// fills its own from the front in submission order, so a slot number orders triangles as they were submitted.  Triangles cut by
 // the clipper keep one such slot (their "order") and put their fan triangles into the extra
 // region that starts at slot 256 * n_blocks.
 
@@ -280,7 +280,7 @@ struct RasterArgs {
     size_t image_stride;        // pixels from one view's image to the next (views render into consecutive images)
     const FrameCounters *counters;
     FrameCounters *host_counters; // host-visible copy of the counters, written by the first workgroup (may be null)
-    const uint8_t *texels;
+    const uint4 *footprints; // the textures as tables of bilinear footprints (TexDev::offset indexes it)
     const TexDev *textures;
     uint32_t n_textures;
     uint8_t *out_color;   // RGBA8, row-major, full frame
@@ -310,5 +310,6 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s);
 hipError_t launch_finish(const FinishArgs &a, hipStream_t s);
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s);
 hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s);
+hipError_t launch_texture_footprints(const uint8_t *texels, uint32_t width, uint32_t height, uint4 *footprints, hipStream_t s);
 
 } // namespace sxe

@@ -135,16 +135,13 @@ __device__ inline uint32_t unorm8_encode(float a)
 // texture(sampler2D, uv) for a single-level RGBA8 sRGB image, linear filter, clamp to edge
 // (standard.frag:12; sampler at src/renderer/drawer.rs:231; format at src/renderer/types.rs:186),
 // split into texel addressing and filtering so that the four fetches of several pixels overlap.
+// The textures are kept as tables of footprints: entry (i, j), i in [-1, width - 1], j in
+// [-1, height - 1], holds the four texels a sample whose upper left texel is (i, j) filters, with
+// the clamp to the edge already applied: texels (i, j), (i + 1, j), (i, j + 1), (i + 1, j + 1).  A
+// pixel's fetch is one 16-byte load from one cache line instead of four loads from two lines.
 struct TexelQuad {
-    uint32_t p0, p1; // texel indices (into the pooled texel buffer) of the pair of neighbours to load from either row
-    bool hi0, hi1;   // the quad's left / right texel is the second of its row's pair
+    uint32_t entry; // index into the pooled footprint tables
     float ax, ay;
-};
-// The two texels of a row of the quad are neighbours in memory unless the clamp made them one and
-// the same, and then a pair that contains it is loaded: two 8-byte loads per pixel instead of four
-// 4-byte ones.  (The texel pool ends with a spare texel for one-texel-wide rows.)
-struct __attribute__((packed, aligned(4))) TexelPair {
-    uint32_t first, second;
 };
 
 __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
@@ -159,17 +156,12 @@ __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
     TexelQuad q;
     q.ax = x - fx0;
     q.ay = y - fy0;
-    const int mw = (int)t.width - 1, mh = (int)t.height - 1;
-    const int ix0 = min(max((int)fx0, 0), mw), ix1 = min(max((int)fx0 + 1, 0), mw);
-    const int iy0 = min(max((int)fy0, 0), mh), iy1 = min(max((int)fy0 + 1, 0), mh);
+    // fx0 is in [-1, width]; at width the weight ax is 0 and the entry of width - 1, whose two
+    // columns are both the last texel, gives the same sums.  Likewise for the rows.
+    const uint32_t i = (uint32_t)(min((int)fx0, (int)t.width - 1) + 1), j = (uint32_t)(min((int)fy0, (int)t.height - 1) + 1);
     // rows and widths are at most 16384 (checked when the textures are set): the full-rate 24-bit
     // multiply gives the same product as the general one, which costs four times as much
-    const uint32_t row0 = t.offset + __umul24((uint32_t)iy0, t.width), row1 = t.offset + __umul24((uint32_t)iy1, t.width);
-    const int base = min(ix0, max(mw - 1, 0));
-    q.p0 = row0 + (uint32_t)base;
-    q.p1 = row1 + (uint32_t)base;
-    q.hi0 = ix0 != base;
-    q.hi1 = ix1 != base;
+    q.entry = t.offset + __umul24(j, t.width + 1u) + i;
     return q;
 }
 
@@ -370,7 +362,6 @@ struct PixelMid { // what the second step needs
 template <bool MANYTEX>
 __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, int32_t tpx, int32_t tpy, const TexDev *s_tex)
 {
-    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
     PixelMid m;
     const int32_t px = tpx + (int32_t)(w.pix & (kTile - 1)), py = tpy + (int32_t)(w.pix / kTile);
     uint32_t slot = w.slot;
@@ -429,9 +420,8 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
         const TexDev td = MANYTEX ? a.textures[ti] : s_tex[ti];
         const TexelQuad tq = texel_quad(td, u, v);
         m.ax = tq.ax; m.ay = tq.ay;
-        const TexelPair a0 = *reinterpret_cast<const TexelPair *>(texels + tq.p0), a1 = *reinterpret_cast<const TexelPair *>(texels + tq.p1);
-        m.t00 = tq.hi0 ? a0.second : a0.first; m.t10 = tq.hi1 ? a0.second : a0.first;
-        m.t01 = tq.hi0 ? a1.second : a1.first; m.t11 = tq.hi1 ? a1.second : a1.first;
+        const uint4 fp = a.footprints[tq.entry];
+        m.t00 = fp.x; m.t10 = fp.y; m.t01 = fp.z; m.t11 = fp.w;
     }
     return m;
 }
@@ -729,6 +719,29 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     SXE_STAMP(7);
 }
 
+// One thread per entry of a texture's footprint table.
+__global__ __launch_bounds__(256) void k_texture_footprints(const uint32_t *__restrict__ texels, uint32_t width, uint32_t height,
+                                                            uint4 *__restrict__ footprints)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_row = (uint64_t)width + 1u;
+    if (idx >= per_row * ((uint64_t)height + 1u)) return;
+    const int i = (int)(idx % per_row) - 1, j = (int)(idx / per_row) - 1;
+    // texture(sampler2D, uv) with clamp to edge (src/renderer/drawer.rs:231): coordinates are clamped texel by texel
+    const uint32_t x0 = (uint32_t)max(i, 0), x1 = (uint32_t)min(i + 1, (int)width - 1);
+    const uint32_t y0 = (uint32_t)max(j, 0), y1 = (uint32_t)min(j + 1, (int)height - 1);
+    const uint32_t *r0 = texels + (size_t)y0 * width, *r1 = texels + (size_t)y1 * width;
+    footprints[idx] = make_uint4(r0[x0], r0[x1], r1[x0], r1[x1]);
+}
+
+hipError_t launch_texture_footprints(const uint8_t *texels, uint32_t width, uint32_t height, uint4 *footprints, hipStream_t s)
+{
+    const uint64_t n = ((uint64_t)width + 1u) * ((uint64_t)height + 1u);
+    hipLaunchKernelGGL(k_texture_footprints, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t *>(texels), width, height, footprints);
+    return hipGetLastError();
+}
+
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s)
 {
     if (a.g.n_tiles == 0) return hipSuccess;
@@ -839,7 +852,6 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
     float depth[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     uint32_t code[4] = {a.clear_code, a.clear_code, a.clear_code, a.clear_code};
     uint32_t prim[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    const uint32_t *texels = reinterpret_cast<const uint32_t *>(a.texels);
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_key[e]);
         const RastRec r = a.rast[rec];
@@ -883,9 +895,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
                 const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
                 const TexDev td = a.textures[h.tex_fan & 0xFFFFFFu];
                 const TexelQuad tq = texel_quad(td, u, v);
-                const TexelPair a0 = *reinterpret_cast<const TexelPair *>(texels + tq.p0), a1 = *reinterpret_cast<const TexelPair *>(texels + tq.p1);
-                filter_quad_rgba(s_dec, s_un, tq.hi0 ? a0.second : a0.first, tq.hi1 ? a0.second : a0.first,
-                                 tq.hi0 ? a1.second : a1.first, tq.hi1 ? a1.second : a1.first, tq.ax, tq.ay, src);
+                const uint4 fp = a.footprints[tq.entry];
+                filter_quad_rgba(s_dec, s_un, fp.x, fp.y, fp.z, fp.w, tq.ax, tq.ay, src);
                 if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
                     const ColorRec c = a.color[rec];
                     src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
