@@ -235,13 +235,19 @@ def main():
         traffic_all = profile_file("pmc_traffic.json") or {}
         valu_all = profile_file("pmc_valu_lds.json") or {}
         valu = next((v for k, v in valu_all.items() if isinstance(v, dict) and ("k_" + dom) in k), {})
+        mem = next((v for k, v in (profile_file("pmc_mem.json") or {}).items() if isinstance(v, dict) and ("k_" + dom) in k), {})
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_all.get(dom),
                     "algorithmic_bytes_per_launch": ab[dom], "avg_ms_per_launch": stage_ms[dom],
                     # what binds the kernel in practice (tools/pmc_valu_lds.sh, profiles/pmc_valu_lds.json):
                     # share of the launch during which the vector ALUs of all SIMDs were issuing
                     "valu_frac": valu.get("valu_busy_frac"), "valu_lane_use": valu.get("valu_lane_use"),
-                    "lds_frac": valu.get("lds_busy_frac")}
+                    "lds_frac": valu.get("lds_busy_frac"),
+                    # the vector-memory pipeline of the compute units (tools/pmc_mem.sh, profiles/pmc_mem.json):
+                    # share of the launch the data-return units were busy, and the L1s were held up by
+                    # requests still on their way to or from the L2
+                    "td_busy_frac": mem.get("td_busy_frac"), "l1_pending_stall_frac": mem.get("tcp_pending_stall_frac"),
+                    "l2_read_requests": mem.get("TCP_TCC_READ_REQ_sum")}
         assert roofline["frac"] <= 1.0, "algorithmic bytes over time exceed the HBM peak: the byte model is wrong"
         stage = {}
         for k in stage_ms:

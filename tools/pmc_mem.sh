@@ -13,4 +13,4 @@ pass() { # name, counters...
 pass ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE
 pass tb TA_FLAT_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_LOAD_WAVEFRONT_sum TD_STORE_WAVEFRONT_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum GRBM_GUI_ACTIVE
 pass tc TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_GUI_ACTIVE
-cd $R && python3 tools/pmc_mem.py $O profiles/pmc_mem.json
+cd $R && python3 tools/pmc_mem.py $O profiles/pmc_mem.json && cp profiles/pmc_mem.json $O/pmc_mem.json

@@ -11,6 +11,8 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wri
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null || exit 1
 bash tools/pmc_valu_lds.sh > $O/pmc_valu_lds.out 2>&1 || exit 1
 cp profiles/pmc_valu_lds.json $O/pmc_valu_lds.json
+bash tools/pmc_mem.sh > $O/pmc_mem.out 2>&1 || exit 1
+cp profiles/pmc_mem.json $O/pmc_mem.json
 # (the counter summaries first: the bench line quotes them)
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 cd $R && timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 > $O/bench.json 2> $O/bench.err || exit 1
