@@ -87,6 +87,26 @@ def test_shading_modes(orc, shading):
     assert_frames_equal(got, ref, what="soup shading %d" % shading)
 
 
+def test_tiny_textures_and_coordinates_beyond_the_edges(orc):
+    """Clamp to edge (the sampler of src/renderer/drawer.rs:231) where it matters most: textures of
+    one texel, one row or one column, odd sizes, and texture coordinates far outside [0, 1], so that
+    samples land on and beyond every border of the texture."""
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(77)
+    sizes = [(1, 1), (1, 7), (5, 1), (3, 2), (2, 2), (17, 9)]  # (width, height)
+    textures = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in sizes]
+    for t in textures:
+        t[..., 3] = 255
+    n_obj, per = len(sizes), 150
+    tris = random_soup(rng, n_obj * per, 128, 128, kinds=("small", "medium", "large", "huge"))
+    uvs = rng.uniform(-0.75, 1.75, size=(n_obj * per * 3, 2)).astype(np.float32)
+    uvs[::7] = rng.choice(np.array([0.0, 1.0, -0.0, 0.5], np.float32), size=uvs[::7].shape)  # exactly on the borders too
+    s = soup_scene(tris, uvs=uvs, textures=textures, width=128, height=128, objects_split=[per] * n_obj,
+                   tex_ids=np.arange(n_obj))
+    ref, got = _soup_pair(orc, s)
+    assert_frames_equal(got, ref, what="tiny textures")
+
+
 def test_scissor_bands_equal_the_full_frame(orc):
     s = scenes.config_scene(2, scale=0.3)
     w, h = s.size
