@@ -535,6 +535,18 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     const uint32_t e4 = e3 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.x);  // + class 1
     const uint32_t e5 = e4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.y);  // + class 0
     const uint32_t n = (a.debug & kDebugSkipRaster) ? 0u : e5;
+    if (e5 == 0u && !DEV) {
+        // nothing was binned to this tile: the clear values, row by row, and that is all
+        for (int k = 0; k < kTilePixels / kRasterThreads; ++k) {
+            const int32_t i = tpx + (tid & (kTile - 1)), j = tpy + (tid / kTile) + k * (kRasterThreads / kTile);
+            if (i > cx1 || j < cy0 || j > cy1) continue;
+            const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
+            reinterpret_cast<uint32_t *>(a.out_color)[p] = a.clear_code;
+            a.out_depth[p] = 1.0f;
+            if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
+        }
+        return;
+    }
     const uint32_t *bin = a.bins + (size_t)(view * a.g.n_tiles + tile) * a.bl.stride;
     // start of each region minus the entries taken before it
     const uint32_t o4 = a.bl.off[4], o3 = a.bl.off[3] - e1, o2 = a.bl.off[2] - e2, o1 = a.bl.off[1] - e3, o0 = a.bl.off[0] - e4;
