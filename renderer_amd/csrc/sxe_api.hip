@@ -732,7 +732,7 @@ void record_stats(sxe_ctx *c, const FrameCounters &k)
 {
     c->stats.prims = c->n_prims;
     c->stats.records = k.total_records;
-    c->stats.bin_entries = k.total_pairs;
+    c->stats.bin_entries = (uint32_t)std::min<unsigned long long>(k.total_pairs, 0xFFFFFFFFull);
     c->stats.tiles = c->g.n_tiles;
     c->stats.instance_vertices = c->n_inst_vertices;
     c->stats.objects = c->n_objects;
@@ -826,7 +826,8 @@ int retire_oldest(sxe_ctx *c)
         uint32_t hopeless = 0, blend_max = 0; // a frame in flight that no regrowth can hold
         for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
             const FrameCounters &k = *c->slots[f % kFrameSlots].h_counters;
-            hopeless |= k.overflow & (kOverflowPairs | kOverflowBlend);
+            hopeless |= k.overflow & kOverflowBlend;
+            if (k.total_pairs > 0xFFFFFFFFull) hopeless |= kOverflowPairs; // (then a region has overflowed as well)
             blend_max = std::max(blend_max, k.blend_max);
         }
         if (hopeless) {
@@ -842,7 +843,11 @@ int retire_oldest(sxe_ctx *c)
             // the oldest frame overflowed; the younger ones are drawn again after it in any case
             for (int attempt = 0; attempt < 4 && (r.h_counters->overflow || (attempt == 0 && f > c->frames_retired)); ++attempt) {
                 int rc = grow_for(c, r);
-                if (rc) return rc;
+                if (rc) { // (out of memory, or bins beyond 2^32 entries) nothing in flight can be finished
+                    for (FrameSlot &x : c->slots) x.pending = false;
+                    c->frames_retired = c->frames_enqueued;
+                    return rc;
+                }
                 c->redraws++;
                 rc = enqueue_frame(c, r, false, context_bufs(c, r));
                 if (rc) return rc;

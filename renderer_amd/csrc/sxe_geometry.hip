@@ -779,11 +779,10 @@ __device__ inline uint32_t tile_cost(const TileCtr &t)
     return (t.cnt[0] + t.cnt[1] + 2u * t.cnt[2] + 8u * t.cnt[3] + 100u * t.multi) >> 2;
 }
 
-// Tiles are ordered in chunks of 4096 (eight per thread), one workgroup per chunk.  A workgroup
-// works out what the other chunks contribute by itself (their class histogram), which costs one
-// more coalesced pass over the counters and no synchronisation between workgroups.
-constexpr uint32_t kOrderChunk = 4096;
+// Tiles are ordered in chunks, a few per thread, one workgroup per chunk.
 constexpr uint32_t kFinishThreads = 512;
+constexpr int kOrderPerThread = 2; // (8: 4 us more for this kernel on a 4K frame; 1: the tile kernel's tail grows)
+constexpr uint32_t kOrderChunk = kFinishThreads * kOrderPerThread;
 
 // Sums are kept in 64 bits: a frame inside the stated limits can hold more than 2^32 (triangle,
 // tile) pairs (a few ten thousand screen-filling triangles on an 8K frame).
@@ -904,9 +903,9 @@ __device__ inline void account(TileTotals &tt, const TileCtr &t, bool on)
 
 // Grid (C = chunks of 4096 tiles):
 //   workgroup 0:           number of surviving triangles;
-//   workgroups 1..C:       launch order of a chunk's tiles and their launch records; the first of
-//                          them also the frame's totals: bin entries, the fullest region of each kind
-//                          over all tiles (what the bins would need), capacity check;
+//   workgroups 1..C:       launch order of a chunk's tiles and their launch records, and the chunk's
+//                          share of the frame's totals: bin entries, the fullest region of each kind
+//                          (what the bins would need), capacity check;
 //   workgroups C+1..:      the late entries, the listed triangles dealt out over all waves, so that
 //                          the dependent memory round trips of a crowd of them (a mesh close to the
 //                          camera) are spread out instead of queueing up in one wave.
@@ -937,81 +936,92 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
         return;
     }
     if (blockIdx.x <= chunks) {
-        // launch order of the tile workgroups: a counting sort by estimated cost, dearest first, so
-        // that the long-running tiles start early and the short ones fill the end of the launch
-        const uint32_t chunk = blockIdx.x - 1u, base = chunk * kOrderChunk;
-        __shared__ uint32_t s_hist[kOrderClasses], s_before[kOrderClasses];
-        if (tid < kOrderClasses) s_hist[tid] = s_before[tid] = 0;
+        // Launch order of the tile workgroups: dearest first by estimated cost, so that the
+        // long-running tiles start early and the short ones fill the end of the launch.  Chunk c
+        // takes tiles c, c + C, c + 2C, ...: every chunk is a sample of the whole frame, orders its
+        // tiles by itself (a counting sort), and the chunks' orders are dealt into the launch
+        // order like hands of cards -- no workgroup needs to know another's tiles.
+        const uint32_t chunk = blockIdx.x - 1u;
+        const uint32_t n_mine = n_tiles > chunk ? (n_tiles - chunk + chunks - 1u) / chunks : 0u; // tiles of this chunk
+        __shared__ uint32_t s_hist[kOrderClasses];
+        if (tid < kOrderClasses) s_hist[tid] = 0;
         __syncthreads();
         TileTotals tt;
         tt.pairs = 0;
         tt.blend_max = 0;
 #pragma unroll
         for (int r = 0; r < kBinRegions; ++r) tt.need[r] = 0;
-        TileCtr mine[8]; // this chunk's tiles: their counters are read once (all eight loads in flight together)
+        TileCtr mine[kOrderPerThread]; // the counters are read once
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mine[k] = a.tiles[min(base + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
+        for (int k = 0; k < kOrderPerThread; ++k)
+            mine[k] = a.tiles[min(((uint32_t)tid + kFinishThreads * (uint32_t)k) * chunks + chunk, last_tile)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool on = base + (uint32_t)tid + kFinishThreads * (uint32_t)k < n_tiles;
+        for (int k = 0; k < kOrderPerThread; ++k) {
+            const bool on = (uint32_t)tid + kFinishThreads * (uint32_t)k < n_mine;
             class_take(s_hist, order_class(tile_cost(mine[k])), on, lane);
             account(tt, mine[k], on);
         }
-        // the other chunks: every tile counts for the class sizes and the totals, the earlier ones
-        // also for this chunk's place inside each class
-        for (uint32_t other = 0; other < chunks; ++other)
-            if (other != chunk) {
-                TileCtr oc[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) oc[k] = a.tiles[min(other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k, last_tile)];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool on = other * kOrderChunk + (uint32_t)tid + kFinishThreads * (uint32_t)k < n_tiles;
-                    const uint32_t cls = order_class(tile_cost(oc[k]));
-                    class_take(s_hist, cls, on, lane);
-                    if (other < chunk) class_take(s_before, cls, on, lane);
-                    account(tt, oc[k], on);
-                }
-            }
         __syncthreads();
         if (wave == 0) {
             // exclusive scan from the dearest class down: lane l holds classes 127 - 2l and 126 - 2l
             static_assert(kOrderClasses == 128, "two classes per lane of one wave");
             const uint32_t h0 = s_hist[kOrderClasses - 1 - 2 * lane], h1 = s_hist[kOrderClasses - 2 - 2 * lane];
             const uint32_t before = wave_inclusive_scan(h0 + h1, lane) - (h0 + h1);
-            s_hist[kOrderClasses - 1 - 2 * lane] = before + s_before[kOrderClasses - 1 - 2 * lane];
-            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0 + s_before[kOrderClasses - 2 - 2 * lane];
+            s_hist[kOrderClasses - 1 - 2 * lane] = before;
+            s_hist[kOrderClasses - 2 - 2 * lane] = before + h0;
         }
         __syncthreads();
+        // The chunks' r-th tiles follow one another; the first `full` ranks exist in every chunk.
+        const uint32_t full = n_tiles / chunks; // (the first n_tiles - full * chunks chunks have one tile more)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + (uint32_t)tid + kFinishThreads * (uint32_t)k;
-            const uint32_t at = class_take(s_hist, order_class(tile_cost(mine[k])), i < n_tiles, lane);
-            if (i < n_tiles) {
+        for (int k = 0; k < kOrderPerThread; ++k) {
+            const uint32_t j = (uint32_t)tid + kFinishThreads * (uint32_t)k;
+            const uint32_t r = class_take(s_hist, order_class(tile_cost(mine[k])), j < n_mine, lane);
+            if (j < n_mine) {
+                const uint32_t i = j * chunks + chunk; // the tile
+                const uint32_t at = r < full ? r * chunks + chunk : full * chunks + chunk; // (rank `full`: only the longer chunks)
                 uint4 *dst = reinterpret_cast<uint4 *>(a.tile_launch + at);
                 const uint32_t view = i / a.g.n_tiles;
                 dst[0] = make_uint4(i - view * a.g.n_tiles, mine[k].multi, mine[k].cnt[3], mine[k].cnt[2]);
                 dst[1] = make_uint4(mine[k].cnt[1], mine[k].cnt[0], view, mine[k].flags);
             }
         }
-        if (chunk == 0) {
-            const unsigned long long pairs = block_sum(tt.pairs, s_part, lane, wave);
-            uint32_t need[kBinRegions];
+        // The frame's totals: every chunk adds its share (one pass through LDS for all seven
+        // figures; lanes 0..6 of the first wave then own one each).
+        __shared__ unsigned long long s_red[kFinishThreads / 64][8];
+        {
+            unsigned long long v = tt.pairs;
+            for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+            uint32_t m[6] = {tt.need[0], tt.need[1], tt.need[2], tt.need[3], tt.need[4], tt.blend_max};
 #pragma unroll
-            for (int r = 0; r < kBinRegions; ++r) need[r] = block_max(tt.need[r], s_part, lane, wave);
-            const uint32_t blend_max = block_max(tt.blend_max, s_part, lane, wave);
-            if (tid == 0) {
-                a.counters->blend_max = blend_max;
-                a.counters->total_pairs = (uint32_t)min(pairs, 0xFFFFFFFFull);
-                uint32_t flags = pairs > 0xFFFFFFFFull ? kOverflowPairs | kOverflowBins : 0u; // beyond any bin array
-                if (blend_max > kBlendMaxEntries) flags |= kOverflowBlend;
+            for (int q = 0; q < 6; ++q)
+                for (int d = 32; d; d >>= 1) m[q] = max(m[q], (uint32_t)__shfl_xor((int)m[q], d));
+            if (lane == 0) {
+                s_red[wave][0] = v;
 #pragma unroll
-                for (int r = 0; r < kBinRegions; ++r) {
-                    a.counters->need[r] = need[r];
-                    if (need[r] > a.bl.cap[r]) flags |= kOverflowBins;
-                }
-                if (flags) atomicOr(&a.counters->overflow, flags);
+                for (int q = 0; q < 6; ++q) s_red[wave][1 + q] = m[q];
             }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            static_assert(kBinRegions == 5, "figures 1..5 are the regions, 6 the ordered path's fullest tile");
+            unsigned long long mine_v = 0;
+            if (lane < 7)
+                for (int w = 0; w < (int)kFinishThreads / 64; ++w)
+                    mine_v = lane == 0 ? mine_v + s_red[w][0] : max(mine_v, s_red[w][lane]);
+            // (a chunk's own figures tell whether a region is too small: the frame's are their maxima)
+            uint32_t flags = 0;
+            if (lane == 0) atomicAdd(&a.counters->total_pairs, mine_v);
+            if (lane >= 1 && lane <= 5) {
+                atomicMax(&a.counters->need[lane - 1], (uint32_t)mine_v);
+                if ((uint32_t)mine_v > pick_region(a.bl.cap, (uint32_t)(lane - 1))) flags = kOverflowBins;
+            }
+            if (lane == 6) {
+                atomicMax(&a.counters->blend_max, (uint32_t)mine_v);
+                if ((uint32_t)mine_v > kBlendMaxEntries) flags = kOverflowBlend;
+            }
+            for (int d = 32; d; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d);
+            if (lane == 0 && flags) atomicOr(&a.counters->overflow, flags);
         }
         return;
     }

@@ -32,7 +32,7 @@ constexpr uint32_t kDebugMask = 63u << 26;
 // overflow bits of FrameCounters::overflow
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
 constexpr uint32_t kOverflowNoClip = 4u; // a triangle needs clipping in a frame enqueued without the clip kernel
-constexpr uint32_t kOverflowPairs = 8u;  // more than 2^32 - 1 (triangle, tile) pairs: beyond any bin array
+constexpr uint32_t kOverflowPairs = 8u;  // more than 2^32 - 1 (triangle, tile) pairs: beyond any bin array (found by the host)
 constexpr uint32_t kOverflowBlend = 16u; // a tile with translucent triangles holds more entries than the ordered path sorts
 // Tiles that hold a triangle with a translucent texture are rendered by k_raster_blend: every
 // fragment is depth-tested and blended in submission order (BlendState::ALPHA,
@@ -122,7 +122,7 @@ struct __attribute__((aligned(16))) ColorRec {
 
 struct FrameCounters {
     uint32_t total_records; // surviving triangles (order slots)
-    uint32_t total_pairs;   // (triangle, tile) bin entries
+    uint32_t unused0;
     uint32_t fan_records;   // fan triangles of clipped primitives
     uint32_t overflow;      // kOverflow* bits
     uint32_t clip_count;    // triangles handed to the clip kernel
@@ -130,6 +130,8 @@ struct FrameCounters {
     uint32_t need[5];       // per bin region: the largest number of entries any tile has for it
     uint32_t blend_max;     // most entries of any tile that takes the ordered (blending) path
     uint32_t pad[4];        // development counters (box census)
+    uint32_t unused1;
+    unsigned long long total_pairs; // (triangle, tile) bin entries of all tiles (may exceed 32 bits: the host checks)
 };
 
 // A triangle that crosses the near, far or a guard-band plane: k_setup reserves its order slot and
