@@ -637,24 +637,35 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
     if (lane == 0) wave_count[wave] = n_alive;
     // ---- triangles cut by the near/far/guard planes keep their slot (it ranks them in submission
     // order) and are queued for k_clip, which fills the slot in ----
-    if (clip) {
-        const uint32_t rank = (uint32_t)__popcll(alive & below), slot = wslot0 + rank;
-        sr[2 * rank] = make_uint4((uint32_t)kNoRaster, 0u, 0u, 0u);
-        sr[2 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
-        ss[3 * rank] = make_uint4(0u, 0u, 0u, 0u);
-        ss[3 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
-        ss[3 * rank + 2] = make_uint4(0u, prim, 0u, 0u);
-        if (!TEX) sc[3 * rank] = sc[3 * rank + 1] = sc[3 * rank + 2] = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t at = atomicAdd(&a.counters->clip_count, 1u);
-        if (a.clip_off) {
-            atomicOr(&a.counters->overflow, kOverflowNoClip);
-        } else if (at < a.fan_capacity) {
-            ClipItem it;
-            it.inst = bd.inst; it.tri = t; it.slot = slot; it.view = view;
-            a.clip_list[at] = it;
-        } else {
-            atomicOr(&a.counters->overflow, kOverflowClip);
+    if (clip_mask) { // (the same for the whole wave)
+        // one place in the queue per wave and atomic: atomics of many lanes or waves on one address
+        // are done one after the other, tens of nanoseconds each
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)clip_mask) - 1;
+        if (lane == leader) base = atomicAdd(&a.counters->clip_count, (uint32_t)__popcll(clip_mask));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        bool no_clip = false, full = false;
+        if (clip) {
+            const uint32_t rank = (uint32_t)__popcll(alive & below), slot = wslot0 + rank;
+            sr[2 * rank] = make_uint4((uint32_t)kNoRaster, 0u, 0u, 0u);
+            sr[2 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
+            ss[3 * rank] = make_uint4(0u, 0u, 0u, 0u);
+            ss[3 * rank + 1] = make_uint4(0u, 0u, 0u, 0u);
+            ss[3 * rank + 2] = make_uint4(0u, prim, 0u, 0u);
+            if (!TEX) sc[3 * rank] = sc[3 * rank + 1] = sc[3 * rank + 2] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t at = base + (uint32_t)__popcll(clip_mask & below);
+            if (a.clip_off) {
+                no_clip = true;
+            } else if (at < a.fan_capacity) {
+                ClipItem it;
+                it.inst = bd.inst; it.tri = t; it.slot = slot; it.view = view;
+                a.clip_list[at] = it;
+            } else {
+                full = true;
+            }
         }
+        const uint32_t flags = (__ballot(no_clip) ? kOverflowNoClip : 0u) | (__ballot(full) ? kOverflowClip : 0u);
+        if (flags && lane == leader) atomicOr(&a.counters->overflow, flags);
     }
     __builtin_amdgcn_wave_barrier();
     // the wave's staged records to its slots (its own LDS writes are done when it reads them back)
@@ -784,30 +795,6 @@ constexpr uint32_t kFinishThreads = 512;
 constexpr int kOrderPerThread = 2; // (8: 4 us more for this kernel on a 4K frame; 1: the tile kernel's tail grows)
 constexpr uint32_t kOrderChunk = kFinishThreads * kOrderPerThread;
 
-// Sums are kept in 64 bits: a frame inside the stated limits can hold more than 2^32 (triangle,
-// tile) pairs (a few ten thousand screen-filling triangles on an 8K frame).
-__device__ inline unsigned long long block_sum(unsigned long long v, unsigned long long *s_part, int lane, int wave)
-{
-    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
-    __syncthreads(); // s_part may still be read from an earlier call
-    if (lane == 0) s_part[wave] = v;
-    __syncthreads();
-    unsigned long long tot = 0;
-    for (int w = 0; w < (int)kFinishThreads / 64; ++w) tot += s_part[w];
-    return tot;
-}
-
-__device__ inline uint32_t block_max(uint32_t v, unsigned long long *s_part, int lane, int wave)
-{
-    for (int d = 32; d; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    __syncthreads();
-    if (lane == 0) s_part[wave] = v;
-    __syncthreads();
-    uint32_t m = 0;
-    for (int w = 0; w < (int)kFinishThreads / 64; ++w) m = max(m, (uint32_t)s_part[w]);
-    return m;
-}
-
 // counter[cls] += 1 for every lane with `on`; returns the value before the lane's own increment.
 // Lanes that share the class of the first such lane (runs of empty or alike tiles are common) go
 // together in one atomic: LDS atomics of one instruction on one address are done one by one.
@@ -902,46 +889,29 @@ __device__ inline void account(TileTotals &tt, const TileCtr &t, bool on)
 }
 
 // Grid (C = chunks of 4096 tiles):
-//   workgroup 0:           number of surviving triangles;
-//   workgroups 1..C:       launch order of a chunk's tiles and their launch records, and the chunk's
+//   workgroups 0..C-1:     launch order of a chunk's tiles and their launch records, and the chunk's
 //                          share of the frame's totals: bin entries, the fullest region of each kind
 //                          (what the bins would need), capacity check;
-//   workgroups C+1..:      the late entries, the listed triangles dealt out over all waves, so that
+//   workgroups C..C+7:     a share of the survivor count each;
+//   workgroups C+8..:      the late entries, the listed triangles dealt out over all waves, so that
 //                          the dependent memory round trips of a crowd of them (a mesh close to the
 //                          camera) are spread out instead of queueing up in one wave.
 constexpr uint32_t kWalkChunk = 16;
+constexpr uint32_t kCountBlocks = 8;
 __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
 {
-    __shared__ unsigned long long s_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_tiles = total_tiles(a.g);       // of all views
     const uint32_t last_tile = max(n_tiles, 1u) - 1u; // (the counter array never holds fewer than one tile)
     const uint32_t chunks = max((n_tiles + kOrderChunk - 1u) / kOrderChunk, 1u);
     const uint32_t n_blocks = a.n_blocks * a.g.views * (kSetupThreads / 64); // (one count per wave of a setup work item)
-    if (blockIdx.x == 0) {
-        // four counts per load, sixteen loads in flight per thread
-        uint32_t sum = 0;
-        const uint32_t n4 = n_blocks / 4u;
-        const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
-        for (uint32_t i = tid; i < n4; i += 16u * kFinishThreads) {
-            uint4 v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = (i + kFinishThreads * k < n4) ? c4[i + kFinishThreads * k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        }
-        if ((uint32_t)tid < n_blocks - 4u * n4) sum += a.blk_count[4u * n4 + tid];
-        const uint32_t records = (uint32_t)block_sum(sum, s_part, lane, wave); // (at most 256 per work item, 2^23 work items)
-        if (tid == 0) a.counters->total_records = records;
-        return;
-    }
-    if (blockIdx.x <= chunks) {
+    if (blockIdx.x < chunks) {
         // Launch order of the tile workgroups: dearest first by estimated cost, so that the
         // long-running tiles start early and the short ones fill the end of the launch.  Chunk c
         // takes tiles c, c + C, c + 2C, ...: every chunk is a sample of the whole frame, orders its
         // tiles by itself (a counting sort), and the chunks' orders are dealt into the launch
         // order like hands of cards -- no workgroup needs to know another's tiles.
-        const uint32_t chunk = blockIdx.x - 1u;
+        const uint32_t chunk = blockIdx.x;
         const uint32_t n_mine = n_tiles > chunk ? (n_tiles - chunk + chunks - 1u) / chunks : 0u; // tiles of this chunk
         __shared__ uint32_t s_hist[kOrderClasses];
         if (tid < kOrderClasses) s_hist[tid] = 0;
@@ -987,7 +957,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
             }
         }
         // The frame's totals: every chunk adds its share (one pass through LDS for all seven
-        // figures; lanes 0..6 of the first wave then own one each).
+        // figures; lanes 0..6 of the first wave then own one each).  The pair total is kept in
+        // 64 bits: a frame inside the stated limits can hold more than 2^32 (triangle, tile) pairs
+        // (a few ten thousand screen-filling triangles on an 8K frame).
         __shared__ unsigned long long s_red[kFinishThreads / 64][8];
         {
             unsigned long long v = tt.pairs;
@@ -1028,7 +1000,34 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
     // Late entries.  A wave takes up to sixteen listed triangles per round; when the list is short,
     // fewer, so that all waves have work (a triangle's entries are one chain of memory round trips
     // per 64 tiles it touches, and chains in one wave run one after the other).
-    const uint32_t wb = blockIdx.x - chunks - 1u;
+    if (blockIdx.x < chunks + kCountBlocks) {
+        // a share of the survivor counts (statistics): four counts per load, sixteen loads in flight
+        // per thread, one atomic per workgroup (atomics on one address are done one after the other)
+        __shared__ uint32_t s_sum[kFinishThreads / 64];
+        const uint32_t cb = blockIdx.x - chunks;
+        const uint32_t n4 = n_blocks / 4u, from = (uint32_t)((unsigned long long)n4 * cb / kCountBlocks),
+                       to = (uint32_t)((unsigned long long)n4 * (cb + 1u) / kCountBlocks);
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(a.blk_count);
+        uint32_t survivors = 0;
+        for (uint32_t i = from + (uint32_t)tid; i < to; i += 16u * kFinishThreads) {
+            uint4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = (i + kFinishThreads * k < to) ? c4[i + kFinishThreads * k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) survivors += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+        if (cb == 0 && (uint32_t)tid < n_blocks - 4u * n4) survivors += a.blk_count[4u * n4 + tid];
+        for (int d = 32; d; d >>= 1) survivors += (uint32_t)__shfl_xor((int)survivors, d);
+        if (lane == 0) s_sum[wave] = survivors;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t all = 0;
+            for (int w = 0; w < (int)kFinishThreads / 64; ++w) all += s_sum[w];
+            if (all) atomicAdd(&a.counters->total_records, all); // (at most 256 per work item, 2^23 work items)
+        }
+        return;
+    }
+    const uint32_t wb = blockIdx.x - chunks - kCountBlocks;
     const uint32_t n_walk = a.counters->walk_count;
     constexpr uint32_t kWaves = kFinishThreads / 64;
     const uint32_t n_waves = a.walk_blocks * kWaves;
@@ -1106,7 +1105,7 @@ hipError_t launch_finish(const FinishArgs &a, hipStream_t s)
 {
     const uint32_t n_tiles = total_tiles(a.g);
     const uint32_t chunks = n_tiles > kOrderChunk ? (n_tiles + kOrderChunk - 1u) / kOrderChunk : 1u;
-    hipLaunchKernelGGL(k_finish, dim3(1u + chunks + a.walk_blocks), dim3(kFinishThreads), 0, s, a);
+    hipLaunchKernelGGL(k_finish, dim3(chunks + kCountBlocks + a.walk_blocks), dim3(kFinishThreads), 0, s, a);
     return hipGetLastError();
 }
 
