@@ -607,7 +607,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
             oa.rot_delta_ms = c->rot_delta_ms;
             c->rot_pending = false;
         }
-        oa.n_zero = (uint32_t)(9 * ntc); // the TileCtr of every tile (8 words), then the late-fill counters
+        oa.n_zero = (uint32_t)((kTileCtrWords + 1) * ntc); // the TileCtr of every tile, then the late-fill counters
         SXE_HIP(c, launch_object(oa, s));
     }
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_OBJECT], s));
@@ -655,7 +655,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     fa.walk_list = w.walk_list;
     fa.fan_order = w.fan_order;
     fa.tiles = sa.tiles;
-    fa.late_fill = w.tile_counters + 8 * ntc;
+    fa.late_fill = w.tile_counters + kTileCtrWords * ntc;
     fa.tile_launch = w.tile_launch;
     fa.bins = w.bins;
     fa.bl = w.bl;
@@ -755,7 +755,7 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     };
     w.counters = reinterpret_cast<FrameCounters *>(take(sizeof(FrameCounters)));
     w.blk_count = reinterpret_cast<uint32_t *>(take(16 * std::max<size_t>(c->n_blocks, 1)));
-    w.tile_counters = reinterpret_cast<uint32_t *>(take(4 * 10 * ntc));
+    w.tile_counters = reinterpret_cast<uint32_t *>(take(4 * (kTileCtrWords + 2) * ntc));
     w.tile_launch = reinterpret_cast<TileLaunch *>(take(sizeof(TileLaunch) * ntc));
     w.pvm = reinterpret_cast<float *>(take(64 * nobj));
     w.visible = reinterpret_cast<uint8_t *>(take(nobj));
@@ -808,7 +808,7 @@ int ensure_views(sxe_ctx *c, uint32_t views)
         SXE_HIP(c, fs.pv_views.reserve(16 * (size_t)views));
     }
     SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(c->n_blocks, 1) * 4 * views));
-    SXE_HIP(c, c->tile_counters.reserve(9 * nt));
+    SXE_HIP(c, c->tile_counters.reserve((kTileCtrWords + 1) * nt));
     SXE_HIP(c, c->tile_launch.reserve(nt));
     SXE_HIP(c, reserve_records(c));
     return set_bin_layout(c, c->bl.cap);
@@ -1031,7 +1031,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
         c->images[i].prim = c->prim_pool.p ? c->prim_pool.p + px * i : nullptr;
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);
-    if ((e = c->tile_counters.reserve(9 * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
+    if ((e = c->tile_counters.reserve((kTileCtrWords + 1) * nt)) != hipSuccess) return bail("hipMalloc(tile counters)", e);
     if ((e = c->tile_launch.reserve(nt)) != hipSuccess) return bail("hipMalloc(tile launch records)", e);
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);

@@ -203,6 +203,7 @@ struct __attribute__((aligned(16))) TileCtr {
     uint32_t flags; // kTileBlend
     uint32_t pad1, pad2;
 };
+constexpr size_t kTileCtrWords = sizeof(TileCtr) / 4;
 __host__ __device__ inline uint32_t bin_reserved(const TileCtr &t) { return t.cnt[0] + t.cnt[1] + t.cnt[2] + t.cnt[3]; }
 __host__ __device__ inline uint32_t bin_size(const TileCtr &t) { return bin_reserved(t) + t.multi; }
 // Size class of a triangle from the number of pixels in its box: <= 2, <= 8, <= 24, more
