@@ -230,7 +230,9 @@ def main():
         covered_px = int((depth[scissor[0]:scissor[1]] < 1.0).sum()) if scissor else int((depth < 1.0).sum())
         ab = algorithmic_bytes(stats, scene, width, rows, covered_px)
         stage_ms = {"setup": kern["setup_ms"], "raster_shade": kern["raster_shade_ms"]}
-        dom = max(stage_ms, key=stage_ms.get)
+        # the two large kernels take the same time to within run-to-run noise: the tile kernel is
+        # reported as long as it is within 5 % of the longest, so that the line does not flip between runs
+        dom = "raster_shade" if stage_ms["raster_shade"] >= 0.95 * stage_ms["setup"] else "setup"
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic_all = profile_file("pmc_traffic.json") or {}
         valu_all = profile_file("pmc_valu_lds.json") or {}
