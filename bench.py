@@ -132,10 +132,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device is visible and there is no CPU path")
+    # SXE_BENCH_REHEARSAL=1: a dry run of the N-rank path where there are fewer GPUs than ranks (the
+    # ranks share the GPUs, gloo carries the exchange through host memory); its line is marked invalid
+    rehearsal = os.environ.get("SXE_BENCH_REHEARSAL", "") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    stat_device = "cpu" if rehearsal else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     scene = scenes.config_scene(args.config, scale=args.scale)
     width, height = scene.size
@@ -205,12 +214,12 @@ def main():
         gather_ms = 0.5 * (pipe.last_gather_ms(last) + pipe.last_gather_ms(last - 1)) if args.steps >= 2 else pipe.last_gather_ms(last)
     per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         mine = torch.tensor([kern["object_ms"], kern["setup_ms"], kern["finish_ms"], kern["raster_shade_ms"], kern["frame_ms"],
                              gather_ms or 0.0, float(stats["records"]), float(stats["bin_entries"]),
-                             float(scissor[1] - scissor[0]) if scissor else float(height)], dtype=torch.float64, device="cuda")
+                             float(scissor[1] - scissor[0]) if scissor else float(height)], dtype=torch.float64, device=stat_device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         names = ["object_ms", "setup_ms", "finish_ms", "raster_shade_ms", "frame_ms", "gather_ms", "records", "bin_entries", "rows"]
@@ -283,6 +292,8 @@ def main():
             result["per_rank"] = per_rank
         if args.scale != 1.0:
             result["invalid"] = "scaled-down debug run"
+        if rehearsal:
+            result["invalid"] = "rehearsal: ranks share GPUs, exchange over gloo through host memory"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, width, height, n_prims)
         if args.check:

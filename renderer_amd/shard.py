@@ -47,6 +47,8 @@ def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None):
     nccl/RCCL backend, a CPU tensor for gloo).  On `dst` the frame is assembled in `out` (a
     (height, width, 4) uint8 tensor on the band's device; allocated when None) and returned;
     other ranks return None.  Ranks whose band is empty take no part in the exchange.
+    CUDA tensors on a gloo group (a rehearsal of several ranks on fewer GPUs) go through host
+    memory: gloo does not send from device memory.
     """
     import torch
     import torch.distributed as dist
@@ -56,20 +58,26 @@ def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None):
     if tuple(band.shape) != (y1 - y0, width, 4) or band.dtype != torch.uint8:
         raise ValueError("band has shape %s, expected %s uint8" % (tuple(band.shape), (y1 - y0, width, 4)))
     band = band.contiguous()
+    via_host = band.is_cuda and world > 1 and dist.get_backend(group) == "gloo"
     if rank != dst:
         if y1 > y0 and world > 1:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, band, dst, group)]):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, band.cpu() if via_host else band, dst, group)]):
                 w.wait()
         return None
     frame = out if out is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
     if tuple(frame.shape) != (height, width, 4) or frame.dtype != torch.uint8 or not frame.is_contiguous():
         raise ValueError("out must be a contiguous (%d, %d, 4) uint8 tensor" % (height, width))
-    ops = [dist.P2POp(dist.irecv, frame[a:b], r, group) for r, (a, b) in enumerate(bands) if r != dst and b > a]
+    senders = [(r, a, b) for r, (a, b) in enumerate(bands) if r != dst and b > a]
+    landing = {r: (torch.empty((b - a, width, 4), dtype=torch.uint8) if via_host else frame[a:b]) for r, a, b in senders}
+    ops = [dist.P2POp(dist.irecv, landing[r], r, group) for r, a, b in senders]
     if y1 > y0:
         frame[y0:y1].copy_(band)
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if via_host:
+        for r, a, b in senders:
+            frame[a:b].copy_(landing[r])
     return frame
 
 
