@@ -705,7 +705,8 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
     }
 }
 
-// (six resident waves per SIMD matter more to this kernel than the last few registers)
+// (58 registers and 20 KB of LDS: eight workgroups per compute unit; the kernel runs the same with
+// seven and 11 % slower with six)
 // DEV: built with the development switches of SetupArgs::debug; the ordinary build has none of
 // their tests in its code.
 // TEX: texture shading only (the usual case), so the colour planes, the loads for them and their
