@@ -107,6 +107,19 @@ def test_tiny_textures_and_coordinates_beyond_the_edges(orc):
     assert_frames_equal(got, ref, what="tiny textures")
 
 
+def test_random_scenes(orc):
+    """A hundred random scenes (tools/fuzz_parity.py: soups of every awkward kind at odd frame sizes,
+    random shading mode, scissor band, object split, tiny textures, some translucent; sphere fields
+    under random cameras): colour, depth and primitive id equal the oracle's in every one."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.run(100, 3, verbose=True) == 0
+
+
 def test_scissor_bands_equal_the_full_frame(orc):
     s = scenes.config_scene(2, scale=0.3)
     w, h = s.size

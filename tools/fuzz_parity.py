@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Development: many random scenes, HIP frame against the oracle's, bit for bit (colour, depth,
+primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode,
+random scissor band, several objects and textures; sphere fields under random cameras.
+
+  fuzz_parity.py [cases] [seed]
+"""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle
+from renderer_amd import api, scenes
+from tests.util import random_soup, soup_scene, render_hip, IDENT
+
+
+
+def run(cases, seed0, verbose=True):
+    """Number of cases whose HIP frame differs from the oracle's."""
+    oracle.build()
+    bad = 0
+    for case in range(cases):
+        bad += 0 if one_case(seed0 * 1000 + case, case, verbose) else 1
+    return bad
+
+
+def one_case(seed, case, verbose):
+    rng = np.random.default_rng(seed)
+    shading = int(rng.integers(0, 3))
+    if case % 3 == 2:
+        s = scenes.config_scene(int(rng.choice([2, 3, 5])), scale=float(rng.uniform(0.03, 0.12)))
+        w, h = s.size
+        s.camera["position"] += rng.uniform(-3, 3, 3).astype(np.float32)
+        models = oracle.to_model(s.transforms)
+        view, proj = oracle.camera(s.camera, w, h)
+        desc = "%s %dx%d" % (s.name, w, h)
+    else:
+        w, h = int(rng.integers(9, 400)), int(rng.integers(9, 300))
+        n = int(rng.integers(1, 1500))
+        n_obj = int(rng.integers(1, 6))
+        split = np.diff(np.sort(np.concatenate([[0, n], rng.integers(0, n + 1, n_obj - 1)]))).tolist()
+        split = [k for k in split if k > 0]
+        tris = random_soup(rng, n, w, h)
+        texs = [rng.integers(0, 256, size=(int(rng.integers(1, 40)), int(rng.integers(1, 40)), 4), dtype=np.uint8) for _ in range(3)]
+        translucent = rng.random() < 0.25  # then the tiles take the ordered (blending) path
+        for k, t in enumerate(texs):
+            if not (translucent and k < 2):
+                t[..., 3] = 255
+        s = soup_scene(tris, uvs=rng.uniform(-0.5, 1.5, (3 * n, 2)), colors=rng.uniform(0, 1, (3 * n, 3)), textures=texs, width=w,
+                       height=h, objects_split=split, tex_ids=rng.integers(0, 3, len(split)))
+        models = np.tile(IDENT, (len(s.objects), 1))
+        view = proj = IDENT
+        desc = "soup %d tris %dx%d %d objects%s" % (n, w, h, len(split), " translucent" if translucent else "")
+    scissor = None
+    if rng.random() < 0.4:
+        a, b = sorted(rng.integers(0, h + 1, 2).tolist())
+        if b > a:
+            scissor = (a, b)
+    ref = oracle.render(s, models, view, proj, w, h, shading=shading, scissor=scissor, threads=8)
+    got = render_hip(s, models=models, view=view, proj=proj, shading=shading, scissor=scissor)
+    y0, y1 = scissor if scissor else (0, h)
+    ok = (np.array_equal(ref["color"][y0:y1], got["color"][y0:y1]) and
+          np.array_equal(ref["depth"][y0:y1].view(np.uint32), got["depth"][y0:y1].view(np.uint32)) and
+          np.array_equal(ref["prim"][y0:y1], got["prim"][y0:y1]))
+    if not ok and verbose:
+        print("MISMATCH case %d: %s shading %d scissor %s" % (case, desc, shading, scissor), flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    bad = run(cases, seed0)
+    print("%d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
