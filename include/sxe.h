@@ -238,7 +238,9 @@ int sxe_read_tile_counts(sxe_ctx *ctx, uint32_t *counts, size_t size_bytes);
 int sxe_read_tile_parts(sxe_ctx *ctx, uint32_t *parts, size_t size_bytes);
 /* Diagnostics: device clock (100 MHz) stamps of every tile's workgroup in the last frame, eight
  * values per tile (0: start, 1: after initialisation, 2-4: coverage phases, 5: compaction,
- * 7: end; 6 unused); only for contexts created with the development flag 1u << 26. */
+ * 7: end; 6 unused; a tile drawn by the ordered blending kernel instead: 0: start, 4: entries
+ * gathered, 1: sorted, 2: entries done, 3: end, and in place of a stamp 5: its number of entries);
+ * only for contexts created with the development flag 1u << 26. */
 int sxe_read_tile_times(sxe_ctx *ctx, uint64_t *clocks, size_t size_bytes);
 int sxe_get_stats(sxe_ctx *ctx, sxe_frame_stats *out);
 

@@ -823,20 +823,27 @@ __device__ inline void filter_quad_rgba(const float *dec, const float *un, uint3
     }
 }
 
-// One workgroup per flagged tile.  The tile's entries are sorted by submission order (a record's
-// rank, then its record number: the fan triangles of a clipped primitive share a rank and follow
-// each other as the fan lists them), then every thread takes them one after the other against the
-// four pixels it owns: coverage, depth test Less with depth write, shading, and
-// BlendState::ALPHA over what the sRGB8 target holds (src/renderer/drawer.rs:660-663,698-705),
-// exactly as the fixed-function pipeline does it one fragment at a time.  Slow next to
-// k_raster_shade (every entry is visited by every wave whose rows its box touches), and only
-// used where the result depends on the order.
+// One workgroup of sixteen waves per flagged tile; a wave owns a block of 8x8 pixels, a thread one
+// pixel.  The tile's entries are sorted by submission order (a record's rank, then its record
+// number: the fan triangles of a clipped primitive share a rank and follow each other as the fan
+// lists them) and their pixel boxes inside the tile worked out.  A wave then visits, in order,
+// only the entries whose box reaches its block: coverage, depth test Less with depth write,
+// shading, and BlendState::ALPHA over what the sRGB8 target holds
+// (src/renderer/drawer.rs:660-663,698-705), exactly as the fixed-function pipeline does it one
+// fragment at a time.  What bounds a crowded tile is the number of instructions its sixteen waves
+// issue on the one compute unit: visits times instructions per visit.
+constexpr int kBlendThreads = 1024;
+
+// flags of an entry's coverage numbers: the biases that the second and third edge function contain; a wide triangle
+constexpr uint32_t kEdgeBias1 = 1u, kEdgeBias2 = 2u, kEdgeWide = 4u;
+
 template <bool COVERAGE>
-__global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
+__global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
 {
     __shared__ unsigned long long s_key[kBlendMaxEntries];
     __shared__ __attribute__((aligned(16))) uint32_t s_enc[kEncPadded];
     __shared__ float s_dec[256], s_un[256];
+    constexpr uint32_t kNoBox = 0xFFFFFFFFu;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.counters->overflow) return;
     const uint4 launch = reinterpret_cast<const uint4 *>(a.tile_launch)[2 * blockIdx.x];
@@ -844,12 +851,16 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
     if (!((uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.w) & kTileBlend)) return;
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.x);
     const uint32_t view = (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.z);
+#define SXE_BSTAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
+    SXE_BSTAMP(0);
     a.out_color += 4 * a.image_stride * view;
     a.out_depth += a.image_stride * view;
     if (COVERAGE) a.out_prim += a.image_stride * view;
-    for (int i = tid; i < kEncPadded; i += kRasterThreads) s_enc[i] = reinterpret_cast<const uint32_t *>(g_srgb_encode)[i];
-    s_dec[tid] = c_srgb_decode[tid];
-    s_un[tid] = c_unorm8[tid];
+    for (int i = tid; i < kEncPadded; i += kBlendThreads) s_enc[i] = reinterpret_cast<const uint32_t *>(g_srgb_encode)[i];
+    if (tid < 256) {
+        s_dec[tid] = c_srgb_decode[tid];
+        s_un[tid] = c_unorm8[tid];
+    }
     const int32_t tpx = (int32_t)(tile % a.g.tiles_x) * kTile;
     const int32_t tpy = (int32_t)(tile / a.g.tiles_x + a.g.tile_row0) * kTile;
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
     uint32_t n = 0;
 #pragma unroll
     for (int r = 0; r < kBinRegions; ++r) {
-        for (uint32_t i = (uint32_t)tid; i < cnt[r]; i += kRasterThreads) {
+        for (uint32_t i = (uint32_t)tid; i < cnt[r]; i += kBlendThreads) {
             const uint32_t rec = bin[a.bl.off[r] + i];
             const uint32_t order = rec < a.n_slots ? rec : a.fan_order[rec - a.n_slots];
             if (n + i < kBlendMaxEntries) s_key[n + i] = ((unsigned long long)order << 32) | rec;
@@ -873,11 +884,16 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
     n = min(n, kBlendMaxEntries); // (k_finish has flagged the frame if a tile holds more)
     uint32_t n_pow2 = 1;
     while (n_pow2 < n) n_pow2 <<= 1;
-    for (uint32_t i = n + (uint32_t)tid; i < n_pow2; i += kRasterThreads) s_key[i] = ~0ull;
+    for (uint32_t i = n + (uint32_t)tid; i < n_pow2; i += kBlendThreads) s_key[i] = ~0ull;
     __syncthreads();
+    SXE_BSTAMP(4);
+    // Bitonic network.  Thread t takes elements t, t + 1024, ...: a step whose stride is below 64
+    // stays inside runs of 64 elements that one wave alone reads and writes, in program order, so
+    // only the steps with longer strides need the workgroup's barrier, before and after.
     for (uint32_t k = 2; k <= n_pow2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = (uint32_t)tid; i < n_pow2; i += kRasterThreads) {
+            if (j >= 64u) __syncthreads();
+            for (uint32_t i = (uint32_t)tid; i < n_pow2; i += kBlendThreads) {
                 const uint32_t partner = i ^ j;
                 if (partner > i) {
                     const unsigned long long x = s_key[i], y = s_key[partner];
@@ -888,91 +904,203 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster_blend(RasterArgs a)
                     }
                 }
             }
-            __syncthreads();
-        }
-
-    // a thread owns pixels (lane & 31, 2 * wave + (lane >> 5) + 8 k), k = 0..3: a wave owns two rows out of every eight
-    const int32_t lx = lane & 31, ly0 = 2 * wave + (lane >> 5);
-    float depth[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    uint32_t code[4] = {a.clear_code, a.clear_code, a.clear_code, a.clear_code};
-    uint32_t prim[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (uint32_t e = 0; e < n; ++e) {
-        const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_key[e]);
-        const RastRec r = a.rast[rec];
-        if (r.x0 == kNoRaster) continue;
-        const Tri t = unpack_tri(r, a.wide, rec);
-        int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-        if (!pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1)) continue;
-        const ShadeRec h = a.shade[rec];
-        // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 with the top-left rule as a bias
-        const long long ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1, ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2, ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-        const long long b0 = edge_bias((int32_t)ex0, (int32_t)ey0), b1 = edge_bias((int32_t)ex1, (int32_t)ey1),
-                        b2 = edge_bias((int32_t)ex2, (int32_t)ey2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int32_t row = tpy + 2 * wave + 8 * k; // the wave's rows of this round: row, row + 1
-            if (row + 1 < by0 || row > by1) continue;   // (the same for the whole wave)
-            const int32_t px = tpx + lx, py = tpy + ly0 + 8 * k;
-            if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
-            const long long sx = 256ll * px + 128, sy = 256ll * py + 128;
-            const long long E0 = ex0 * (sy - t.y1) - ey0 * (sx - t.x1);
-            const long long E1 = ex1 * (sy - t.y2) - ey1 * (sx - t.x2);
-            const long long E2 = ex2 * (sy - t.y0) - ey2 * (sx - t.x0);
-            if (((E0 - b0) | (E1 - b1) | (E2 - b2)) < 0) continue;
-            const float l1 = (float)E1 * r.rA, l2 = (float)E2 * r.rA;
-            const float z = clamp_depth((r.z0 + l1 * r.dz1) + l2 * r.dz2);
-            if (!(z < 1.0f)) continue;      // can never be Less than the cleared 1.0
-            if (!(z < depth[k])) continue;  // Comparison::Less, src/renderer/drawer.rs:700
-            depth[k] = z;
-            prim[k] = h.prim;
-            const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
-            const float riw = 1.0f / iw;
-            float src[4];
-            if (a.shading == SXE_SHADE_VERTEX_COLOR) {
-                const ColorRec c = a.color[rec];
-                src[0] = ((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw;
-                src[1] = ((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw;
-                src[2] = ((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw;
-                src[3] = 1.0f;
+            if (j >= 64u) {
+                __syncthreads();
             } else {
-                const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
-                const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
-                const TexDev td = a.textures[h.tex_fan & 0xFFFFFFu];
-                const TexelQuad tq = texel_quad(td, u, v);
-                const uint4 fp = a.footprints[tq.entry];
-                filter_quad_rgba(s_dec, s_un, fp.x, fp.y, fp.z, fp.w, tq.ax, tq.ay, src);
-                if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
-                    const ColorRec c = a.color[rec];
-                    src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
-                    src[1] = (((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw) * src[1];
-                    src[2] = (((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw) * src[2];
-                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            // BlendState::ALPHA on an sRGB8 target: the destination is what the target holds
-            const float sa = src[3], ia = 1.0f - sa;
-            const float dr = s_dec[code[k] & 255u], dg = s_dec[(code[k] >> 8) & 255u], db = s_dec[(code[k] >> 16) & 255u];
-            const float da = s_un[code[k] >> 24];
-            const uint32_t cr = srgb_encode_lds(s_enc, src[0] * sa + dr * ia);
-            const uint32_t cg = srgb_encode_lds(s_enc, src[1] * sa + dg * ia);
-            const uint32_t cb = srgb_encode_lds(s_enc, src[2] * sa + db * ia);
-            code[k] = cr | (cg << 8) | (cb << 16) | (unorm8_encode(sa + da * ia) << 24);
+        }
+    __syncthreads();
+
+    SXE_BSTAMP(1);
+    // Every entry's pixel box inside the tile takes the place of its rank in the key: the order is
+    // settled, and the waves choose their entries by the box.
+    for (uint32_t i = (uint32_t)tid; i < n; i += kBlendThreads) {
+        const uint32_t rec = (uint32_t)s_key[i];
+        const RastRec r = a.rast[rec];
+        uint32_t box = kNoBox;
+        if (r.x0 != kNoRaster) {
+            const Tri t = unpack_tri(r, a.wide, rec);
+            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+            if (pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1))
+                box = (uint32_t)(bx0 - tpx) | ((uint32_t)(by0 - tpy) << 8) | ((uint32_t)(bx1 - tpx) << 16) | ((uint32_t)(by1 - tpy) << 24);
+        }
+        s_key[i] = ((unsigned long long)box << 32) | rec;
+    }
+    __syncthreads();
+
+    // The tile is 4x4 blocks of 8x8 pixels and every wave owns one: a small triangle reaches one or two waves.
+    // Which wave owns which block turns by one column from one row of blocks to the next: waves 0, 4, 8, 12 share an
+    // execution unit, and a crowded corner of the tile should not land on one unit alone.
+    // From here on the waves go their own ways, without a barrier, until the tile is written.
+    const int32_t wy = wave >> 2, wx = (wave + wy) & 3;
+    const int32_t tx = 8 * wx + (lane & 7), ty = 8 * wy + (lane >> 3); // in the tile
+    const int32_t px = tpx + tx, py = tpy + ty;
+    const int32_t sx = 256 * px + 128, sy = 256 * py + 128;
+    float depth = 1.0f;
+    uint32_t code = a.clear_code, prim = 0xFFFFFFFFu;
+    // A fragment that has passed the depth test waits in its lane, its texels on their way, until
+    // another one arrives for the same lane or the entries end: filtering and blending cost more
+    // than coverage and depth do, small triangles each reach a few lanes only, and waiting lets
+    // one pass of that code serve the fragments of many entries.  Only the order of a pixel's own
+    // fragments matters, and a lane never holds two.
+    bool pend = false;
+    uint32_t pend_rec = 0u;
+    float pend_l1 = 0.0f, pend_l2 = 0.0f;
+    auto blend_pending = [&]() {
+        if (!pend) return;
+        pend = false;
+        const ShadeRec h = a.shade[pend_rec];
+        prim = h.prim;
+        const float l1 = pend_l1, l2 = pend_l2;
+        const float iw = (h.iw0 + l1 * h.diw1) + l2 * h.diw2;
+        const float riw = 1.0f / iw;
+        float src[4];
+        if (a.shading == SXE_SHADE_VERTEX_COLOR) {
+            const ColorRec c = a.color[pend_rec];
+            src[0] = ((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw;
+            src[1] = ((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw;
+            src[2] = ((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw;
+            src[3] = 1.0f;
+        } else {
+            const float u = ((h.uw0 + l1 * h.duw1) + l2 * h.duw2) * riw;
+            const float v = ((h.vw0 + l1 * h.dvw1) + l2 * h.dvw2) * riw;
+            const TexelQuad tq = texel_quad(a.textures[h.tex_fan & 0xFFFFFFu], u, v);
+            const uint4 fp = a.footprints[tq.entry];
+            filter_quad_rgba(s_dec, s_un, fp.x, fp.y, fp.z, fp.w, tq.ax, tq.ay, src);
+            if (a.shading == SXE_SHADE_COLOR_TIMES_TEXTURE) {
+                const ColorRec c = a.color[pend_rec];
+                src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
+                src[1] = (((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw) * src[1];
+                src[2] = (((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw) * src[2];
+            }
+        }
+        // BlendState::ALPHA on an sRGB8 target: the destination is what the target holds
+        const float sa = src[3], ia = 1.0f - sa;
+        const float dr = s_dec[code & 255u], dg = s_dec[(code >> 8) & 255u], db = s_dec[(code >> 16) & 255u];
+        const float da = s_un[code >> 24];
+        const uint32_t cr = srgb_encode_lds(s_enc, src[0] * sa + dr * ia);
+        const uint32_t cg = srgb_encode_lds(s_enc, src[1] * sa + dg * ia);
+        const uint32_t cb = srgb_encode_lds(s_enc, src[2] * sa + db * ia);
+        code = cr | (cg << 8) | (cb << 16) | (unorm8_encode(sa + da * ia) << 24);
+    };
+    // Sixty-four entries of the tile at a time, one per lane.  A lane whose entry reaches the
+    // wave's blocks fetches the triangle and works out, once, what the coverage test of
+    // any pixel needs; the wave then takes those entries in order, each one's numbers read from
+    // its lane.  The fetch for the next sixty-four is under way while these are visited.
+    auto fetch = [&](uint32_t base, unsigned long long &key, bool &reaches, RastRec &r) {
+        key = base + (uint32_t)lane < n ? s_key[base + (uint32_t)lane] : ~0ull;
+        const uint32_t box = (uint32_t)(key >> 32);
+        const int32_t X0 = (int32_t)((box >> 3) & 31u), X1 = (int32_t)((box >> 19) & 31u); // block columns and rows of the box
+        const int32_t Y0 = (int32_t)((box >> 11) & 31u), Y1 = (int32_t)(box >> 27);
+        reaches = box != kNoBox && X0 <= wx && X1 >= wx && Y0 <= wy && Y1 >= wy;
+        r = RastRec{};
+        if (reaches) r = a.rast[(uint32_t)key];
+    };
+    const auto from_lane = [](float v, int from) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), from)); };
+    unsigned long long key_next = 0ull;
+    bool reaches_next = false;
+    RastRec r_next;
+    fetch(0u, key_next, reaches_next, r_next);
+    for (uint32_t base = 0; base < n; base += 64) {
+        const unsigned long long key = key_next;
+        const bool reaches = reaches_next;
+        const RastRec r = r_next;
+        if (base + 64 < n) fetch(base + 64, key_next, reaches_next, r_next);
+        unsigned long long todo = __ballot(reaches);
+        if (!todo) continue;
+        // A narrow triangle's biased edge functions (inside: all three >= 0) at pixel (x, y) of the
+        // tile are c + a x + b y; every term is exact in 32 bits, the values at the pixels of the
+        // triangle's box are the ones edge_start() gives, and a and b fit 24 bits.  A wide
+        // triangle keeps its first corner and offsets in (a0, b0, c0, a1) instead.
+        const uint32_t box_l = (uint32_t)(key >> 32);
+        int32_t a0 = r.x0, b0 = r.y0, c0 = (int32_t)r.d1, a1 = (int32_t)r.d2, b1 = 0, c1 = 0, a2 = 0, b2 = 0, c2 = 0;
+        uint32_t flags_l = kEdgeWide;
+        if (reaches && r.d1 != kWideTri) {
+            const Tri t = unpack_tri(r, a.wide, (uint32_t)key);
+            const int32_t ox = (int32_t)(box_l & 255u), oy = (int32_t)((box_l >> 8) & 255u);
+            const EdgeStart es = edge_start(t, tpx + ox, tpy + oy);
+            a0 = -256 * es.ey0; b0 = 256 * es.ex0; c0 = es.R0 - mul_narrow(a0, ox) - mul_narrow(b0, oy);
+            a1 = -256 * es.ey1; b1 = 256 * es.ex1; c1 = es.R1 - mul_narrow(a1, ox) - mul_narrow(b1, oy);
+            a2 = -256 * es.ey2; b2 = 256 * es.ex2; c2 = es.R2 - mul_narrow(a2, ox) - mul_narrow(b2, oy);
+            flags_l = (es.b1 ? kEdgeBias1 : 0u) | (es.b2 ? kEdgeBias2 : 0u);
+        }
+        while (todo) {
+            const int from = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t box = (uint32_t)__builtin_amdgcn_readlane((int)box_l, from);
+            const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)flags_l, from);
+            const int32_t A0 = __builtin_amdgcn_readlane(a0, from), B0 = __builtin_amdgcn_readlane(b0, from), C0 = __builtin_amdgcn_readlane(c0, from);
+            const int32_t A1 = __builtin_amdgcn_readlane(a1, from);
+            const float z0 = from_lane(r.z0, from), dz1 = from_lane(r.dz1, from), dz2 = from_lane(r.dz2, from), rA = from_lane(r.rA, from);
+            const bool in_box = (tx >= (int32_t)(box & 255u)) & (tx <= (int32_t)((box >> 16) & 255u)) & (ty >= (int32_t)((box >> 8) & 255u)) &
+                                (ty <= (int32_t)(box >> 24));
+            bool inside;
+            float l1, l2;
+            if (!(flags & kEdgeWide)) {
+                const int32_t B1 = __builtin_amdgcn_readlane(b1, from), C1 = __builtin_amdgcn_readlane(c1, from);
+                const int32_t A2 = __builtin_amdgcn_readlane(a2, from), B2 = __builtin_amdgcn_readlane(b2, from), C2 = __builtin_amdgcn_readlane(c2, from);
+                const int32_t E0 = mul_narrow(A0, tx) + (mul_narrow(B0, ty) + C0);
+                const int32_t E1 = mul_narrow(A1, tx) + (mul_narrow(B1, ty) + C1);
+                const int32_t E2 = mul_narrow(A2, tx) + (mul_narrow(B2, ty) + C2);
+                inside = (E0 | E1 | E2) >= 0;
+                l1 = (float)(E1 + (int32_t)(flags & kEdgeBias1)) * rA;
+                l2 = (float)(E2 + (int32_t)((flags >> 1) & 1u)) * rA;
+            } else {
+                // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 with the top-left rule as a bias
+                RastRec rw;
+                rw.x0 = A0; rw.y0 = B0; rw.d1 = (uint32_t)C0; rw.d2 = (uint32_t)A1;
+                const Tri t = unpack_tri(rw, a.wide, (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from));
+                const long long ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1, ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2, ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+                const long long E0 = ex0 * ((long long)sy - t.y1) - ey0 * ((long long)sx - t.x1);
+                const long long E1 = ex1 * ((long long)sy - t.y2) - ey1 * ((long long)sx - t.x2);
+                const long long E2 = ex2 * ((long long)sy - t.y0) - ey2 * ((long long)sx - t.x0);
+                inside = ((E0 - edge_bias((int32_t)ex0, (int32_t)ey0)) | (E1 - edge_bias((int32_t)ex1, (int32_t)ey1)) |
+                          (E2 - edge_bias((int32_t)ex2, (int32_t)ey2))) >= 0;
+                l1 = (float)E1 * rA;
+                l2 = (float)E2 * rA;
+            }
+            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+            // below the cleared 1.0, and Comparison::Less against what is there (src/renderer/drawer.rs:700)
+            const bool want = in_box & inside & (z < 1.0f) & (z < depth);
+            if (!__ballot(want)) continue;
+            if (__ballot(want && pend)) blend_pending();
+            const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from);
+            if (want) {
+                depth = z;
+                pend = true;
+                pend_rec = rec;
+                pend_l1 = l1;
+                pend_l2 = l2;
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int32_t px = tpx + lx, py = tpy + ly0 + 8 * k;
-        if (px > cx1 || py < cy0 || py > cy1) continue;
-        const size_t p = (size_t)(__umul24((uint32_t)py, a.g.width) + (uint32_t)px);
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = code[k];
-        a.out_depth[p] = depth[k];
-        if (COVERAGE) a.out_prim[p] = prim[k];
+    blend_pending();
+    // out through LDS (the sort keys are done with), so that the stores run along the rows
+    __syncthreads();
+    SXE_BSTAMP(2);
+    if (a.tile_times && tid == 0) a.tile_times[8 * tile + 5] = n;
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_key);
+    s_out[ty * kTile + tx] = code;
+    s_out[kTile * kTile + ty * kTile + tx] = __float_as_uint(depth);
+    if (COVERAGE) s_out[2 * kTile * kTile + ty * kTile + tx] = prim;
+    __syncthreads();
+    const int32_t ox = tpx + (tid & 31), oy = tpy + (tid >> 5);
+    if (ox <= cx1 && oy >= cy0 && oy <= cy1) {
+        const size_t p = (size_t)(__umul24((uint32_t)oy, a.g.width) + (uint32_t)ox);
+        reinterpret_cast<uint32_t *>(a.out_color)[p] = s_out[tid];
+        a.out_depth[p] = __uint_as_float(s_out[kTile * kTile + tid]);
+        if (COVERAGE) a.out_prim[p] = s_out[2 * kTile * kTile + tid];
     }
+    SXE_BSTAMP(3);
+#undef SXE_BSTAMP
 }
 
 hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s)
 {
     if (a.g.n_tiles == 0 || !a.blend_scene) return hipSuccess;
-    const dim3 grid(total_tiles(a.g)), block(kRasterThreads);
+    const dim3 grid(total_tiles(a.g)), block(kBlendThreads);
     if (a.out_prim)
         hipLaunchKernelGGL(k_raster_blend<true>, grid, block, 0, s, a);
     else
