@@ -786,6 +786,22 @@ def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
             ref = orc.render(s, models, view, proj, 160, 96)
             got = {"color": d.read_color(v), "depth": d.read_depth(v), "prim": d.read_coverage(v)}
             assert_frames_equal(got, ref, what="translucent view %d" % v)
+    # tiles of one to four thousand entries (every sorting thread then holds several keys)
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    for n, seed in ((9000, 5), (19000, 6)):
+        rng = np.random.default_rng(seed)
+        tris = np.zeros((n, 3, 3), np.float32)
+        tris[..., :2] = rng.uniform(-0.2, 0.2, (n, 1, 2)) + rng.uniform(-0.03, 0.03, (n, 3, 2))
+        tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
+        crowd = soup_scene(tris, width=128, height=128, textures=[scenes.translucent_texture(64, 2)])
+        ref = orc.render(crowd, ident[None], ident, ident, 128, 128)
+        with api.HipDrawer(128, 128, coverage=True) as d:
+            d.update_scene(crowd)
+            d.update_camera_matrices(ident, ident)
+            d.draw(0)
+            got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+            assert 1024 < d.tile_counts().max() <= 4096
+        assert_frames_equal(got, ref, what="crowded translucent tiles, %d triangles" % n)
     # more than 4096 entries in a tile that needs ordering: refused, not rendered wrong
     rng = np.random.default_rng(77)
     n = 32000  # about 6000 surviving entries in each of the four tiles around the centre
@@ -793,7 +809,6 @@ def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
     tris[..., :2] = rng.uniform(-0.2, 0.2, (n, 1, 2)) + rng.uniform(-0.03, 0.03, (n, 3, 2))
     tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
     dense = soup_scene(tris, width=128, height=128, textures=[scenes.translucent_texture(64, 2)])
-    ident = np.eye(4, dtype=np.float32).reshape(16)
     with api.HipDrawer(128, 128) as d:
         d.update_scene(dense)
         d.update_camera_matrices(ident, ident)
