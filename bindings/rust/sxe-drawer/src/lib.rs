@@ -78,6 +78,12 @@ impl HipDrawer {
         check(self.ctx, unsafe { sys::sxe_set_textures(self.ctx, descs.as_ptr(), descs.len() as u32) })
     }
 
+    /// The light of `SXE_SHADE_LIT`: an extension without a counterpart in the reference, whose
+    /// shaders have no lighting.
+    pub fn set_light(&mut self, light: &sys::sxe_light) -> Result<(), String> {
+        check(self.ctx, unsafe { sys::sxe_set_light(self.ctx, light) })
+    }
+
     /// src/renderer/drawer.rs:458-494
     pub fn update_drawables(&mut self, drawables: Vec<Drawable>) -> Result<(), String> {
         let flat: Vec<sys::sxe_drawable> = drawables

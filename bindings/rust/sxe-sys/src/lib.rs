@@ -11,6 +11,8 @@ pub const SXE_E_STATE: c_int = -4;
 pub const SXE_SHADE_TEXTURE: u32 = 0;
 pub const SXE_SHADE_VERTEX_COLOR: u32 = 1;
 pub const SXE_SHADE_COLOR_TIMES_TEXTURE: u32 = 2;
+/// Flat Blinn-Phong over the texture: an extension, the reference's shaders have no lighting.
+pub const SXE_SHADE_LIT: u32 = 3;
 
 pub const SXE_FLAG_WRITE_COVERAGE: u32 = 1;
 pub const SXE_FLAG_TIMING: u32 = 2;
@@ -117,6 +119,18 @@ pub struct sxe_frame_stats {
     pub redraws: u32,
 }
 
+/// Light of `SXE_SHADE_LIT` (no counterpart in the reference); see `sxe_set_light` in include/sxe.h.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct sxe_light {
+    pub to_light: [f32; 3],
+    pub to_viewer: [f32; 3],
+    pub ambient: f32,
+    pub diffuse: f32,
+    pub specular: f32,
+    pub shininess_log2: u32,
+}
+
 extern "C" {
     pub fn sxe_default_config(cfg: *mut sxe_config, width: u32, height: u32);
     pub fn sxe_create(cfg: *const sxe_config, out: *mut *mut sxe_ctx) -> c_int;
@@ -158,6 +172,9 @@ extern "C" {
     pub fn sxe_transform_translate(t: *mut sxe_transform, x: f32, y: f32, z: f32);
     pub fn sxe_transform_rotate(t: *mut sxe_transform, x: f32, y: f32, z: f32);
     pub fn sxe_transform_to_model(t: *const sxe_transform, model: *mut f32);
+    pub fn sxe_default_light(light: *mut sxe_light);
+    pub fn sxe_set_light(ctx: *mut sxe_ctx, light: *const sxe_light) -> c_int;
+    pub fn sxe_light_vectors(light: *const sxe_light, to_light: *mut f32, to_viewer: *mut f32, half: *mut f32) -> c_int;
     pub fn sxe_camera_matrices(camera: *const sxe_transform, fov_deg: f32, aspect: f32, z_near: f32, z_far: f32, view: *mut f32, proj: *mut f32);
     pub fn sxe_srgb_encode_host(x: *const f32, codes: *mut u8, n: usize) -> c_int;
 }

@@ -35,6 +35,9 @@ extern "C" {
 #define SXE_SHADE_TEXTURE 0u
 #define SXE_SHADE_VERTEX_COLOR 1u
 #define SXE_SHADE_COLOR_TIMES_TEXTURE 2u
+/* An extension without a counterpart in the reference, whose shaders have no lighting and whose
+ * Vertex has no normal: flat Blinn-Phong over the texture, see sxe_set_light. */
+#define SXE_SHADE_LIT 3u
 
 #define SXE_FLAG_WRITE_COVERAGE 1u /* keep a per-pixel primitive-id buffer (parity tests) */
 #define SXE_FLAG_TIMING 2u         /* bracket every kernel with HIP events (sxe_get_timings) */
@@ -243,6 +246,31 @@ int sxe_read_tile_parts(sxe_ctx *ctx, uint32_t *parts, size_t size_bytes);
  * only for contexts created with the development flag 1u << 26. */
 int sxe_read_tile_times(sxe_ctx *ctx, uint64_t *clocks, size_t size_bytes);
 int sxe_get_stats(sxe_ctx *ctx, sxe_frame_stats *out);
+
+/* Light of SXE_SHADE_LIT (no counterpart in the reference).  One directional light and a viewer at
+ * infinity, both directions given in world space and normalised by the library; every triangle
+ * is lit as a whole with the normal of its face: n = normalize(cross(w1 - w0, w2 - w0)) of its
+ * corners' world positions (model * position), turned towards the viewer when it faces away
+ * (faces are never culled, src/renderer/drawer.rs:653-657, so both sides are seen), then
+ *   a = ambient + diffuse * max(n . to_light, 0)
+ *   s = specular * max(n . h, 0)^(2^shininess_log2),   h = normalize(to_light + to_viewer)
+ *   rgb = texture.rgb * a + s,   alpha = texture.a
+ * in fp32, every product and sum rounded on its own, the power by repeated squaring.  A triangle
+ * without area in world space gets a = ambient, s = 0.  The defaults are the ones of
+ * sxe_default_light. */
+typedef struct sxe_light {
+    float to_light[3];
+    float to_viewer[3];
+    float ambient, diffuse, specular;
+    uint32_t shininess_log2; /* at most 16 */
+} sxe_light;
+void sxe_default_light(sxe_light *light);
+/* Takes effect with the next frame drawn.  SXE_E_INVALID for a direction of length zero or one
+ * that is not finite, and for shininess_log2 above 16. */
+int sxe_set_light(sxe_ctx *ctx, const sxe_light *light);
+/* The unit vectors the kernels use (host arithmetic, no device needed): towards the light, towards
+ * the viewer, and the half vector between them.  Returns SXE_E_INVALID as sxe_set_light does. */
+int sxe_light_vectors(const sxe_light *light, float to_light[3], float to_viewer[3], float half[3]);
 
 /* ---- host-side Transform / camera maths (no device needed) ---- */
 void sxe_transform_identity(sxe_transform *t);                           /* transform.rs:24-30 */

@@ -208,6 +208,14 @@ class HipDrawer final : public Drawer {
         return rc == SXE_OK ? Status::Ok() : Status::Err(message(ctx_, rc));
     }
 
+    // The light of SXE_SHADE_LIT: not part of the trait either, and without a counterpart in the
+    // reference, whose shaders have no lighting.
+    Status set_light(const sxe_light &light)
+    {
+        const int rc = sxe_set_light(ctx_, &light);
+        return rc == SXE_OK ? Status::Ok() : Status::Err(message(ctx_, rc));
+    }
+
     sxe_ctx *context() const { return ctx_; }
     const Viewport &viewport() const { return viewport_; }
     const std::vector<Drawable> &last_drawables() const { return last_drawables_; }

@@ -18,14 +18,18 @@ TRANSFORM = np.dtype([("position", "<f4", 3), ("scale", "<f4", 3), ("rotation", 
 MESH = np.dtype([("first_vertex", "<u4"), ("n_vertices", "<u4"), ("first_index", "<u4"), ("n_indices", "<u4")])
 OBJECT = np.dtype([("mesh", "<u4"), ("texture", "<i4"), ("rendered", "<u4")])
 
-SHADE_TEXTURE, SHADE_VERTEX_COLOR, SHADE_COLOR_TIMES_TEXTURE = 0, 1, 2
+SHADE_TEXTURE, SHADE_VERTEX_COLOR, SHADE_COLOR_TIMES_TEXTURE, SHADE_LIT = 0, 1, 2, 3
+# the light of SHADE_LIT (an extension without a reference counterpart): the defaults of sxe_default_light
+DEFAULT_LIGHT = dict(to_light=(0.3, 0.8, 0.5), to_viewer=(0.0, 0.0, 1.0), ambient=0.2, diffuse=0.7, specular=0.3, shininess_log2=5)
 FLAG_NO_TRIVIAL_REJECT = 1
 
 
 class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("clear", C.c_float * 4),
                 ("scissor_y0", C.c_uint32), ("scissor_y1", C.c_uint32),
-                ("shading", C.c_uint32), ("flags", C.c_uint32)]
+                ("shading", C.c_uint32), ("flags", C.c_uint32),
+                ("to_light", C.c_float * 3), ("to_viewer", C.c_float * 3),
+                ("ambient", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float), ("shininess_log2", C.c_uint32)]
 
 
 class Texture(C.Structure):
@@ -194,12 +198,14 @@ def camera(cam_transform, width, height, fovy_deg=45.0, near=0.1, far=1000.0):
 
 
 def render(scene, models, view, proj, width, height, clear=(0.7, 0.2, 0.0, 1.0), scissor=None,
-           shading=SHADE_TEXTURE, flags=0, want_clip=False, threads=0):
+           shading=SHADE_TEXTURE, flags=0, want_clip=False, threads=0, light=None):
     """Render one frame of `scene` (renderer_amd.scenes.Scene-like: .vertices .indices .meshes
     .objects .textures). Returns dict(color, depth, prim, clip, stats)."""
     L = lib()
     y0, y1 = scissor if scissor is not None else (0, height)
-    cfg = Config(width, height, (C.c_float * 4)(*clear), y0, y1, shading, flags)
+    lt = dict(DEFAULT_LIGHT, **(light or {}))
+    cfg = Config(width, height, (C.c_float * 4)(*clear), y0, y1, shading, flags, (C.c_float * 3)(*lt["to_light"]),
+                 (C.c_float * 3)(*lt["to_viewer"]), lt["ambient"], lt["diffuse"], lt["specular"], lt["shininess_log2"])
     vertices = np.ascontiguousarray(scene.vertices, dtype=VERTEX)
     indices = np.ascontiguousarray(scene.indices, dtype=np.uint32)
     meshes = np.ascontiguousarray(scene.meshes, dtype=MESH)

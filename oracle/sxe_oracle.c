@@ -428,8 +428,58 @@ static void sample_texture(const orc_texture *t, float u, float v, float out[4])
     }
 }
 
+/* ---- the lighting extension (no reference counterpart; definition at sxe_set_light in include/sxe.h) ---- */
+typedef struct { float l[3], v[3], h[3]; int ok; } light_vectors;
+
+static int unit_vector(const float v[3], float out[3])
+{
+    float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (!(len > 0.0f) || !(len <= 3.0e38f)) return 0;
+    out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len;
+    return 1;
+}
+
+static light_vectors make_light_vectors(const orc_config *cfg)
+{
+    light_vectors L;
+    memset(&L, 0, sizeof L);
+    L.ok = unit_vector(cfg->to_light, L.l) && unit_vector(cfg->to_viewer, L.v) && cfg->shininess_log2 <= 16;
+    if (L.ok) {
+        float sum[3] = { L.l[0] + L.v[0], L.l[1] + L.v[1], L.l[2] + L.v[2] };
+        if (!unit_vector(sum, L.h)) L.h[0] = L.h[1] = L.h[2] = 0.0f;
+    }
+    return L;
+}
+
+/* The two terms of one triangle: rgb = texture.rgb * out[0] + out[1]. */
+static void light_terms(const orc_config *cfg, const light_vectors *L, const float m[16], const float *p0,
+                        const float *p1, const float *p2, float out[2])
+{
+    const float *p[3] = { p0, p1, p2 };
+    float w[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) w[k][r] = ((m[r] * p[k][0] + m[4 + r] * p[k][1]) + m[8 + r] * p[k][2]) + m[12 + r];
+    float e1x = w[1][0] - w[0][0], e1y = w[1][1] - w[0][1], e1z = w[1][2] - w[0][2];
+    float e2x = w[2][0] - w[0][0], e2y = w[2][1] - w[0][1], e2z = w[2][2] - w[0][2];
+    float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    out[0] = cfg->ambient; out[1] = 0.0f;
+    if (!(len > 0.0f) || !(len <= 3.0e38f)) return;
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    float facing = (nx * L->v[0] + ny * L->v[1]) + nz * L->v[2];
+    if (facing < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+    float ndl = (nx * L->l[0] + ny * L->l[1]) + nz * L->l[2];
+    float ndh = (nx * L->h[0] + ny * L->h[1]) + nz * L->h[2];
+    if (!(ndl > 0.0f)) ndl = 0.0f;
+    if (!(ndh > 0.0f)) ndh = 0.0f;
+    float spec = ndh;
+    for (uint32_t k = 0; k < cfg->shininess_log2; ++k) spec = spec * spec;
+    out[0] = cfg->ambient + cfg->diffuse * ndl;
+    out[1] = cfg->specular * spec;
+}
+
 /* One (sub-)triangle with clip-space vertices: setup, coverage, depth test, shade, blend. */
-static void raster_triangle(frame *f, const cvert tri[3], uint32_t prim_id, int32_t texture)
+static void raster_triangle(frame *f, const cvert tri[3], uint32_t prim_id, int32_t texture, const float lit[2])
 {
     const orc_config *cfg = f->cfg;
     float half_w = (float)cfg->width * 0.5f, half_h = (float)cfg->height * 0.5f;
@@ -517,6 +567,8 @@ static void raster_triangle(frame *f, const cvert tri[3], uint32_t prim_id, int3
                 sample_texture(&f->textures[texture], at[0], at[1], src); /* standard.frag:12 */
                 if (cfg->shading == ORC_SHADE_COLOR_TIMES_TEXTURE) { /* ui.frag:12 */
                     src[0] = at[2] * src[0]; src[1] = at[3] * src[1]; src[2] = at[4] * src[2];
+                } else if (cfg->shading == ORC_SHADE_LIT) { /* (extension) */
+                    src[0] = src[0] * lit[0] + lit[1]; src[1] = src[1] * lit[0] + lit[1]; src[2] = src[2] * lit[0] + lit[1];
                 }
             }
             /* BlendState::ALPHA on an sRGB8 target: the destination is what the target holds. */
@@ -539,6 +591,8 @@ static int validate(const orc_config *cfg, const orc_mesh *meshes, uint32_t n_me
 {
     if (!cfg || cfg->width == 0 || cfg->height == 0 || cfg->width > 8192 || cfg->height > 8192) return -1;
     if (cfg->scissor_y0 > cfg->scissor_y1 || cfg->scissor_y1 > cfg->height) return -1;
+    if (cfg->shading > ORC_SHADE_LIT) return -1;
+    if (cfg->shading == ORC_SHADE_LIT && !make_light_vectors(cfg).ok) return -1;
     for (uint32_t m = 0; m < n_meshes; ++m) {
         if (meshes[m].n_indices % 3) return -1;
         for (uint32_t k = 0; k < meshes[m].n_indices; ++k)
@@ -621,6 +675,7 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
         }
     }
 
+    light_vectors light = make_light_vectors(cfg);
     uint32_t *order = draw_order(objects, n_objects);
     uint32_t prim_id = 0;
     for (uint32_t d = 0; d < n_objects; ++d) {
@@ -631,7 +686,12 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
         orc_mat4_mul(pv, models + 16 * (size_t)o, pvm);
         for (uint32_t t = 0; t < m->n_indices / 3; ++t, ++prim_id) {
             cvert poly[12];
+            float lit[2] = { 0.0f, 0.0f };
             f.st.prims++;
+            if (cfg->shading == ORC_SHADE_LIT)
+                light_terms(cfg, &light, models + 16 * (size_t)o, vertices[m->first_vertex + indices[m->first_index + 3 * t]].pos,
+                            vertices[m->first_vertex + indices[m->first_index + 3 * t + 1]].pos,
+                            vertices[m->first_vertex + indices[m->first_index + 3 * t + 2]].pos, lit);
             for (int k = 0; k < 3; ++k) {
                 const orc_vertex *v = &vertices[m->first_vertex + indices[m->first_index + 3 * t + k]];
                 transform_vertex(pvm, v->pos, poly[k].c);
@@ -664,7 +724,7 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
             }
             for (int s = 1; s + 1 < n; ++s) { /* fan; sub-triangle index s-1 */
                 cvert tri[3] = { poly[0], poly[s], poly[s + 1] };
-                raster_triangle(&f, tri, prim_id, objects[o].texture);
+                raster_triangle(&f, tri, prim_id, objects[o].texture, lit);
             }
         }
     }

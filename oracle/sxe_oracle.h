@@ -55,7 +55,10 @@ typedef struct {
     uint32_t width, height;
 } orc_texture;
 
-enum { ORC_SHADE_TEXTURE = 0, ORC_SHADE_VERTEX_COLOR = 1, ORC_SHADE_COLOR_TIMES_TEXTURE = 2 };
+/* ORC_SHADE_LIT has no counterpart in the reference (standard.frag has no lighting, Vertex has no
+ * normal): it restates the flat Blinn-Phong extension that include/sxe.h defines at sxe_set_light,
+ * so that the kernels have something to be compared with.  Parity unpinned, like everything here. */
+enum { ORC_SHADE_TEXTURE = 0, ORC_SHADE_VERTEX_COLOR = 1, ORC_SHADE_COLOR_TIMES_TEXTURE = 2, ORC_SHADE_LIT = 3 };
 enum { ORC_FLAG_NO_TRIVIAL_REJECT = 1 };
 
 typedef struct {
@@ -64,6 +67,10 @@ typedef struct {
     uint32_t scissor_y0, scissor_y1; /* rows [y0, y1) rendered; full frame = [0, height) */
     uint32_t shading;
     uint32_t flags;
+    /* ORC_SHADE_LIT only: directions in world space (any length > 0), terms, exponent 2^shininess_log2 */
+    float to_light[3], to_viewer[3];
+    float ambient, diffuse, specular;
+    uint32_t shininess_log2;
 } orc_config;
 
 typedef struct {

@@ -20,6 +20,7 @@ MESH = np.dtype([("first_vertex", "<u4"), ("n_vertices", "<u4"), ("first_index",
 OBJECT = np.dtype([("mesh", "<u4"), ("texture", "<i4"), ("rendered", "<u4")])
 
 SHADE_TEXTURE, SHADE_VERTEX_COLOR, SHADE_COLOR_TIMES_TEXTURE = 0, 1, 2
+SHADE_LIT = 3  # flat Blinn-Phong over the texture: an extension, the reference's shaders have no lighting
 FLAG_WRITE_COVERAGE, FLAG_TIMING = 1, 2
 E_INVALID, E_DEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4
 
@@ -30,8 +31,31 @@ EXPORTS = [
     "sxe_read_color", "sxe_map_color", "sxe_read_depth", "sxe_read_coverage", "sxe_read_clip_positions", "sxe_read_models",
     "sxe_read_transforms", "sxe_color_device_ptr", "sxe_stream", "sxe_get_timings", "sxe_get_timing_totals", "sxe_reset_timing_totals", "sxe_set_timing_stride", "sxe_get_stats", "sxe_read_tile_counts", "sxe_read_tile_parts", "sxe_read_tile_times",
     "sxe_transform_identity", "sxe_transform_translate", "sxe_transform_rotate", "sxe_transform_to_model",
-    "sxe_camera_matrices", "sxe_srgb_encode_host",
+    "sxe_camera_matrices", "sxe_srgb_encode_host", "sxe_default_light", "sxe_set_light", "sxe_light_vectors",
 ]
+
+
+def make_light(to_light=None, to_viewer=None, ambient=None, diffuse=None, specular=None, shininess_log2=None):
+    """An sxe_light: the library's defaults with the given fields replaced."""
+    lt = Light()
+    lib().sxe_default_light(C.byref(lt))
+    if to_light is not None:
+        lt.to_light = (C.c_float * 3)(*to_light)
+    if to_viewer is not None:
+        lt.to_viewer = (C.c_float * 3)(*to_viewer)
+    for name, value in (("ambient", ambient), ("diffuse", diffuse), ("specular", specular), ("shininess_log2", shininess_log2)):
+        if value is not None:
+            setattr(lt, name, value)
+    return lt
+
+
+def light_vectors(light):
+    """(to_light, to_viewer, half) unit vectors of an sxe_light, as the kernels use them."""
+    out = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+    rc = lib().sxe_light_vectors(C.byref(light), _p(out[0]), _p(out[1]), _p(out[2]))
+    if rc != 0:
+        raise SxeError(rc, "not a usable light")
+    return out
 
 
 class SxeError(RuntimeError):
@@ -82,6 +106,12 @@ class Timings(C.Structure):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Light(C.Structure):
+    """sxe_light: the light of SHADE_LIT."""
+    _fields_ = [("to_light", C.c_float * 3), ("to_viewer", C.c_float * 3), ("ambient", C.c_float), ("diffuse", C.c_float),
+                ("specular", C.c_float), ("shininess_log2", C.c_uint32)]
+
+
 class FrameStats(C.Structure):
     _fields_ = [("prims", C.c_uint64), ("records", C.c_uint64), ("bin_entries", C.c_uint64),
                 ("tiles", C.c_uint64), ("instance_vertices", C.c_uint64), ("objects", C.c_uint64),
@@ -112,6 +142,10 @@ def lib():
         L.sxe_destroy.restype = None
         L.sxe_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sxe_update_drawables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.sxe_default_light.argtypes = [C.POINTER(Light)]
+        L.sxe_default_light.restype = None
+        L.sxe_set_light.argtypes = [C.c_void_p, C.POINTER(Light)]
+        L.sxe_light_vectors.argtypes = [C.POINTER(Light), C.c_void_p, C.c_void_p, C.c_void_p]
         L.sxe_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.sxe_update_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sxe_update_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -266,6 +300,10 @@ class HipDrawer:
                 raise SxeError(E_INVALID, "texture %d is not HxWx4 uint8" % i)
             arr[i] = TextureDesc(t.ctypes.data, t.shape[1], t.shape[0])
         self._check(self._L.sxe_set_textures(self._ctx, arr, len(texs)))
+
+    def set_light(self, to_light=None, to_viewer=None, ambient=None, diffuse=None, specular=None, shininess_log2=None):
+        """The light of SHADE_LIT; what is left out keeps the library's default."""
+        self._check(self._L.sxe_set_light(self._ctx, C.byref(make_light(to_light, to_viewer, ambient, diffuse, specular, shininess_log2))))
 
     def update_drawables(self, drawables):
         arr = (DrawableC * max(1, len(drawables)))()

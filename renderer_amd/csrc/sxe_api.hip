@@ -158,6 +158,7 @@ struct sxe_ctx {
     DevBuf<uint4> footprints;  // (width + 1) x (height + 1) bilinear footprints per texture, back to back
     DevBuf<TexDev> textab;
     Mat4 view, proj, pv;
+    LightDev light; // of SXE_SHADE_LIT
 
     // per-frame work buffers
     DevBuf<uint32_t> blk_count, tile_counters /* a TileCtr per tile | late-fill counter per tile | launch order */, bins, object_mesh, walk_list, fan_order;
@@ -619,6 +620,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.insts = c->insts.p;
     sa.blocks = c->blocks.p;
     sa.pvm = w.pvm;
+    sa.models = c->models.p;
+    sa.light = c->light;
     sa.visible = w.visible;
     sa.n_objects = c->n_objects;
     sa.n_blocks = c->n_blocks;
@@ -950,13 +953,15 @@ void sxe_default_config(sxe_config *cfg, uint32_t width, uint32_t height)
 
 const char *sxe_last_error(const sxe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static bool light_for_device(const sxe_light *light, sxe::LightDev &d);
+
 int sxe_create(const sxe_config *cfg, sxe_ctx **out)
 {
     if (!cfg || !out) return fail(nullptr, SXE_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->width == 0 || cfg->height == 0 || cfg->width > SXE_MAX_DIM || cfg->height > SXE_MAX_DIM)
         return fail(nullptr, SXE_E_INVALID, "frame size %ux%u outside 1..%u", cfg->width, cfg->height, SXE_MAX_DIM);
-    if (cfg->shading > SXE_SHADE_COLOR_TIMES_TEXTURE) return fail(nullptr, SXE_E_INVALID, "unknown shading mode %u", cfg->shading);
+    if (cfg->shading > SXE_SHADE_LIT) return fail(nullptr, SXE_E_INVALID, "unknown shading mode %u", cfg->shading);
     if (!(cfg->fov_deg > 0.0f && cfg->fov_deg < 180.0f) || !(cfg->z_near > 0.0f) || !(cfg->z_far > cfg->z_near))
         return fail(nullptr, SXE_E_INVALID, "bad perspective parameters");
     sxe_config k = *cfg;
@@ -995,6 +1000,11 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     c->view = identity();
     c->proj = identity();
     c->pv = identity();
+    {
+        sxe_light light;
+        sxe_default_light(&light);
+        light_for_device(&light, c->light);
+    }
     auto bail = [&](const char *what, hipError_t err) {
         fail(nullptr, SXE_E_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
         sxe_destroy(c);
@@ -1601,6 +1611,58 @@ void sxe_transform_to_model(const sxe_transform *t, float model[16])
     const Quat q = {t->rotation[0], t->rotation[1], t->rotation[2], t->rotation[3]};
     const Mat4 M = model_matrix(t->position, t->scale, q);
     memcpy(model, M.m, 64);
+}
+
+void sxe_default_light(sxe_light *light)
+{
+    if (!light) return;
+    light->to_light[0] = 0.3f; light->to_light[1] = 0.8f; light->to_light[2] = 0.5f;
+    light->to_viewer[0] = 0.0f; light->to_viewer[1] = 0.0f; light->to_viewer[2] = 1.0f;
+    light->ambient = 0.2f;
+    light->diffuse = 0.7f;
+    light->specular = 0.3f;
+    light->shininess_log2 = 5u;
+}
+
+static bool unit_vector(const float v[3], float out[3])
+{
+    const float len = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    if (!(len > 0.0f) || !(len <= 3.0e38f)) return false;
+    out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len;
+    return true;
+}
+
+int sxe_light_vectors(const sxe_light *light, float to_light[3], float to_viewer[3], float half[3])
+{
+    if (!light || !to_light || !to_viewer || !half || light->shininess_log2 > 16u) return SXE_E_INVALID;
+    if (!unit_vector(light->to_light, to_light) || !unit_vector(light->to_viewer, to_viewer)) return SXE_E_INVALID;
+    const float sum[3] = {to_light[0] + to_viewer[0], to_light[1] + to_viewer[1], to_light[2] + to_viewer[2]};
+    if (!unit_vector(sum, half)) half[0] = half[1] = half[2] = 0.0f; // (light straight behind the viewer's back: no highlight)
+    return SXE_OK;
+}
+
+static bool light_for_device(const sxe_light *light, sxe::LightDev &d)
+{
+    float l[3], v[3], h[3];
+    if (sxe_light_vectors(light, l, v, h) != SXE_OK) return false;
+    if (!(fabsf(light->ambient) <= 3.0e38f) || !(fabsf(light->diffuse) <= 3.0e38f) || !(fabsf(light->specular) <= 3.0e38f)) return false;
+    d.lx = l[0]; d.ly = l[1]; d.lz = l[2];
+    d.hx = h[0]; d.hy = h[1]; d.hz = h[2];
+    d.vx = v[0]; d.vy = v[1]; d.vz = v[2];
+    d.ambient = light->ambient; d.diffuse = light->diffuse; d.specular = light->specular;
+    d.shininess_log2 = light->shininess_log2;
+    return true;
+}
+
+int sxe_set_light(sxe_ctx *c, const sxe_light *light)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    sxe::LightDev d;
+    if (!light || !light_for_device(light, d))
+        return fail(c, SXE_E_INVALID, "light: directions must be finite and not zero, the terms finite, shininess_log2 at most 16");
+    c->light = d; // (kernel arguments of the frames drawn from now on)
+    return SXE_OK;
 }
 
 void sxe_camera_matrices(const sxe_transform *camera, float fov_deg, float aspect, float z_near, float z_far,

@@ -349,9 +349,36 @@ __device__ inline WideRec wide_record(const ScreenTri &s)
     return w;
 }
 
+// SXE_SHADE_LIT: the two lighting terms of a triangle, from the world positions of its corners
+// (p0, p1, p2 in object space, m the object's column-major model matrix): ambient + diffuse and
+// specular, the face's normal turned towards the viewer.  Every product and sum is rounded on its
+// own, in the order written, so that a CPU restatement gives the same bits.
+__device__ inline float2 light_terms(const float *m, const float *p0, const float *p1, const float *p2, const LightDev &L)
+{
+    float w[3][3];
+    const float *p[3] = {p0, p1, p2};
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) w[k][r] = ((m[r] * p[k][0] + m[4 + r] * p[k][1]) + m[8 + r] * p[k][2]) + m[12 + r];
+    const float e1x = w[1][0] - w[0][0], e1y = w[1][1] - w[0][1], e1z = w[1][2] - w[0][2];
+    const float e2x = w[2][0] - w[0][0], e2y = w[2][1] - w[0][1], e2z = w[2][2] - w[0][2];
+    float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 0.0f) || !(len <= 3.0e38f)) return make_float2(L.ambient, 0.0f);
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    const float facing = (nx * L.vx + ny * L.vy) + nz * L.vz;
+    if (facing < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+    float ndl = (nx * L.lx + ny * L.ly) + nz * L.lz;
+    float ndh = (nx * L.hx + ny * L.hy) + nz * L.hz;
+    if (!(ndl > 0.0f)) ndl = 0.0f;
+    if (!(ndh > 0.0f)) ndh = 0.0f;
+    float spec = ndh;
+    for (uint32_t k = 0; k < L.shininess_log2; ++k) spec = spec * spec;
+    return make_float2(L.ambient + L.diffuse * ndl, L.specular * spec);
+}
+
 // The colour planes (scenes shaded with vertex colours): cr/cg/cb are the plain per-corner colours
 // in the original corner order.
-__device__ inline ColorRec color_record(const ScreenTri &s, Attr3 cr, Attr3 cg, Attr3 cb)
+__device__ inline ColorRec color_record(const ScreenTri &s, Attr3 cr, Attr3 cg, Attr3 cb, float2 lit)
 {
     if (s.swapped) {
         float t;
@@ -366,13 +393,15 @@ __device__ inline ColorRec color_record(const ScreenTri &s, Attr3 cr, Attr3 cg, 
     c.rw0 = r0; c.drw1 = r1 - r0; c.drw2 = r2 - r0;
     c.gw0 = g0; c.dgw1 = g1 - g0; c.dgw2 = g2 - g0;
     c.bw0 = b0; c.dbw1 = b1 - b0; c.dbw2 = b2 - b0;
-    c.pad0 = c.pad1 = c.pad2 = 0.0f;
+    c.lit_a = lit.x;
+    c.lit_s = lit.y;
+    c.pad2 = 0.0f;
     return c;
 }
 
 // All records of one screen triangle, straight to slot `rec`.
 __device__ inline void write_records(const SetupArgs &a, uint32_t rec, const ScreenTri &s, uint32_t prim,
-                                     int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb)
+                                     int32_t texture, Attr3 u, Attr3 v, Attr3 cr, Attr3 cg, Attr3 cb, float2 lit)
 {
     RastRec r;
     ShadeRec h;
@@ -380,7 +409,7 @@ __device__ inline void write_records(const SetupArgs &a, uint32_t rec, const Scr
     a.rast[rec] = r;
     a.shade[rec] = h;
     if (!narrow(s.t)) a.wide[rec] = wide_record(s);
-    if (a.shading != SXE_SHADE_TEXTURE) a.color[rec] = color_record(s, cr, cg, cb);
+    if (a.shading != SXE_SHADE_TEXTURE) a.color[rec] = color_record(s, cr, cg, cb, lit);
 }
 
 // One atomic per tile of the box: used for triangles that span several tiles and for fan triangles.
@@ -616,11 +645,13 @@ __device__ inline void setup_block(const SetupArgs &a, const uint32_t block, con
                     const uint32_t *ip = a.indices + bd.idx_base + 3 * (size_t)t;
                     const sxe_vertex &w0 = a.vertices[bd.vtx_base + ip[0]], &w1 = a.vertices[bd.vtx_base + ip[1]],
                                      &w2 = a.vertices[bd.vtx_base + ip[2]];
+                    float2 lit = make_float2(0.0f, 0.0f);
+                    if (a.shading == SXE_SHADE_LIT) lit = light_terms(a.models + 16 * (size_t)bd.object, w0.pos, w1.pos, w2.pos, a.light);
                     const ColorRec c = color_record(st, {w0.color[0], w1.color[0], w2.color[0]}, {w0.color[1], w1.color[1], w2.color[1]},
-                                                    {w0.color[2], w1.color[2], w2.color[2]});
+                                                    {w0.color[2], w1.color[2], w2.color[2]}, lit);
                     sc[3 * rank] = make_uint4(__float_as_uint(c.rw0), __float_as_uint(c.drw1), __float_as_uint(c.drw2), __float_as_uint(c.gw0));
                     sc[3 * rank + 1] = make_uint4(__float_as_uint(c.dgw1), __float_as_uint(c.dgw2), __float_as_uint(c.bw0), __float_as_uint(c.dbw1));
-                    sc[3 * rank + 2] = make_uint4(__float_as_uint(c.dbw2), 0u, 0u, 0u);
+                    sc[3 * rank + 2] = make_uint4(__float_as_uint(c.dbw2), __float_as_uint(c.lit_a), __float_as_uint(c.lit_s), 0u);
                 }
                 if (!is_narrow) a.wide[slot] = wide_record(st);
 
@@ -743,6 +774,10 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         poly[k].c[4] = w.uv[0]; poly[k].c[5] = w.uv[1];
         poly[k].c[6] = w.color[0]; poly[k].c[7] = w.color[1]; poly[k].c[8] = w.color[2];
     }
+    float2 lit = make_float2(0.0f, 0.0f); // (of the whole triangle: its pieces lie in the same plane)
+    if (a.shading == SXE_SHADE_LIT)
+        lit = light_terms(a.models + 16 * (size_t)inst.object, a.vertices[mesh.vtx_base + ip[0]].pos, a.vertices[mesh.vtx_base + ip[1]].pos,
+                          a.vertices[mesh.vtx_base + ip[2]].pos, a.light);
     const int n_poly = clip_polygon(poly, tmp, 3);
     const uint32_t n_fan = n_poly >= 3 ? (uint32_t)(n_poly - 2) : 0u;
     const uint32_t fan0 = n_fan ? atomicAdd(&a.counters->fan_records, n_fan) : 0u;
@@ -774,7 +809,7 @@ __global__ __launch_bounds__(64) void k_clip(SetupArgs a)
         }
         Attr3 u = {q0.c[4] * v0.rw, q1.c[4] * v1.rw, q2.c[4] * v2.rw}, v = {q0.c[5] * v0.rw, q1.c[5] * v1.rw, q2.c[5] * v2.rw};
         Attr3 cr = {q0.c[6], q1.c[6], q2.c[6]}, cg = {q0.c[7], q1.c[7], q2.c[7]}, cb = {q0.c[8], q1.c[8], q2.c[8]};
-        write_records(a, rec, s2, prim, inst.texture, u, v, cr, cg, cb);
+        write_records(a, rec, s2, prim, inst.texture, u, v, cr, cg, cb, lit);
         count_box(a, it.view, s2, translucent_texture(a, inst.texture));
         a.walk_list[atomicAdd(&a.counters->walk_count, 1u)] = rec; // (clipping is rare: one atomic per fan triangle)
     }

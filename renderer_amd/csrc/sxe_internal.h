@@ -117,7 +117,18 @@ struct __attribute__((aligned(16))) ShadeRec {
 struct __attribute__((aligned(16))) ColorRec {
     float rw0, drw1, drw2, gw0;
     float dgw1, dgw2, bw0, dbw1;
-    float dbw2, pad0, pad1, pad2;
+    float dbw2;
+    float lit_a, lit_s; // SXE_SHADE_LIT: the triangle's two lighting terms, rgb = texture.rgb * lit_a + lit_s
+    float pad2;
+};
+
+// The light of SXE_SHADE_LIT as the setup kernels take it: unit vectors in world space.
+struct LightDev {
+    float lx, ly, lz; // towards the light
+    float hx, hy, hz; // half vector between light and viewer
+    float vx, vy, vz; // towards the viewer
+    float ambient, diffuse, specular;
+    uint32_t shininess_log2;
 };
 
 struct FrameCounters {
@@ -220,6 +231,8 @@ struct SetupArgs {
     const InstDev *insts;
     const BlockDesc *blocks;
     const float *pvm;          // 16 floats per object (caller order), per view
+    const float *models;       // 16 floats per object (caller order): read by SXE_SHADE_LIT only
+    LightDev light;
     const uint8_t *visible;
     uint32_t n_objects;
     uint32_t n_blocks;         // per view

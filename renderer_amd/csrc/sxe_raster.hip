@@ -447,6 +447,11 @@ __device__ inline void shade_end(const RasterArgs &a, const PixelMid &m, const f
             src[0] = (((c.rw0 + m.l1 * c.drw1) + m.l2 * c.drw2) * m.riw) * src[0];
             src[1] = (((c.gw0 + m.l1 * c.dgw1) + m.l2 * c.dgw2) * m.riw) * src[1];
             src[2] = (((c.bw0 + m.l1 * c.dbw1) + m.l2 * c.dbw2) * m.riw) * src[2];
+        } else if (a.shading == SXE_SHADE_LIT) {
+            const float4 lit = reinterpret_cast<const float4 *>(&a.color[m.slot])[2]; // (dbw2, lit_a, lit_s, -)
+            src[0] = src[0] * lit.y + lit.z;
+            src[1] = src[1] * lit.y + lit.z;
+            src[2] = src[2] * lit.y + lit.z;
         }
     }
     // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target:
@@ -974,6 +979,11 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
                 src[0] = (((c.rw0 + l1 * c.drw1) + l2 * c.drw2) * riw) * src[0];
                 src[1] = (((c.gw0 + l1 * c.dgw1) + l2 * c.dgw2) * riw) * src[1];
                 src[2] = (((c.bw0 + l1 * c.dbw1) + l2 * c.dbw2) * riw) * src[2];
+            } else if (a.shading == SXE_SHADE_LIT) {
+                const float4 lit = reinterpret_cast<const float4 *>(&a.color[pend_rec])[2]; // (dbw2, lit_a, lit_s, -)
+                src[0] = src[0] * lit.y + lit.z;
+                src[1] = src[1] * lit.y + lit.z;
+                src[2] = src[2] * lit.y + lit.z;
             }
         }
         // BlendState::ALPHA on an sRGB8 target: the destination is what the target holds

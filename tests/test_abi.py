@@ -171,7 +171,7 @@ def test_rust_declarations_cover_the_header():
     align = {"u8": 1, "i32": 4, "u32": 4, "f32": 4, "u64": 8, "*": 8, "sxe_transform": 4, "sxe_vertex": 4}
     want = {"sxe_vertex": 32, "sxe_transform": 40, "sxe_config": C.sizeof(api.Config), "sxe_drawable": C.sizeof(api.DrawableC),
             "sxe_timings": C.sizeof(api.Timings), "sxe_frame_stats": C.sizeof(api.FrameStats), "sxe_texture_desc": 16,
-            "sxe_mesh_desc": 32, "sxe_instance": 52}
+            "sxe_mesh_desc": 32, "sxe_instance": 52, "sxe_light": C.sizeof(api.Light)}
     for name, expect in want.items():
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs, re.S).group(1)
         off, biggest = 0, 1

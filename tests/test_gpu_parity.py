@@ -87,6 +87,54 @@ def test_shading_modes(orc, shading):
     assert_frames_equal(got, ref, what="soup shading %d" % shading)
 
 
+def test_lit_shading(orc):
+    """SXE_SHADE_LIT, the flat Blinn-Phong extension (no reference counterpart: parity is with the
+    oracle's restatement of the definition in include/sxe.h): cube, sphere field under two lights,
+    clipped soup, translucent textures, a set of views, and the light's validation."""
+    from tests.util import random_soup, soup_scene
+    lights = [None, dict(to_light=(-1.0, 0.2, 0.3), to_viewer=(0.2, 0.1, 1.0), ambient=0.05, diffuse=0.9, specular=0.6, shininess_log2=3),
+              dict(to_light=(0.0, -1.0, 0.0), specular=0.0, shininess_log2=0)]
+    c = scenes.cube_scene(320, 240)
+    s = scenes.config_scene(2, scale=0.3)
+    for light in lights:
+        for scene in (c, s):
+            ref = render_oracle(orc, scene, shading=api.SHADE_LIT, light=light)
+            got = render_hip(scene, shading=api.SHADE_LIT, light=light)
+            assert_frames_equal(got, ref, what="lit %s, light %r" % (scene.name, light))
+    plain = render_oracle(orc, s)
+    assert (plain["prim"] == ref["prim"]).all() and not np.array_equal(plain["color"], ref["color"])
+    # triangles cut by the near plane and the guard band keep their face's terms
+    rng = np.random.default_rng(12)
+    w, h = 200, 120
+    soup = soup_scene(random_soup(rng, 900, w, h), width=w, height=h)
+    ref, got = _soup_pair(orc, soup, shading=api.SHADE_LIT)
+    assert ref["stats"]["prims_clipped"] > 30
+    assert_frames_equal(got, ref, what="lit soup")
+    # lit and blended
+    t = scenes.config_scene(2, scale=0.3)
+    t.textures = [t.textures[0], scenes.translucent_texture(128, 5), t.textures[2], scenes.translucent_texture(64, 6)]
+    ref = render_oracle(orc, t, shading=api.SHADE_LIT, light=lights[1])
+    got = render_hip(t, shading=api.SHADE_LIT, light=lights[1])
+    assert_frames_equal(got, ref, what="lit, two of four textures translucent")
+    # a set of views shares the light
+    v = scenes.sphere_field_scene(20, 4, 5.0, (-14.0, -4.0), 160, 96, n_textures=2, tex_size=64, name="views")
+    cams = scenes.orbit_cameras(4, 9, radius=12.0, target=(0.0, 0.0, -9.0))
+    models = orc.to_model(v.transforms)
+    with api.HipDrawer(160, 96, n_images=4, coverage=True, shading=api.SHADE_LIT) as d:
+        d.update_scene(v)
+        d.set_light(**lights[1])
+        d.draw_views(cams)
+        for k in range(4):
+            view, proj = orc.camera(cams[k:k + 1], 160, 96)
+            ref = orc.render(v, models, view, proj, 160, 96, shading=api.SHADE_LIT, light=lights[1])
+            got = {"color": d.read_color(k), "depth": d.read_depth(k), "prim": d.read_coverage(k)}
+            assert_frames_equal(got, ref, what="lit view %d" % k)
+        for bad in (dict(to_light=(0, 0, 0)), dict(to_viewer=(float("inf"), 0, 0)), dict(shininess_log2=17), dict(ambient=float("nan"))):
+            with pytest.raises(api.SxeError) as e:
+                d.set_light(**bad)
+            assert e.value.code == api.E_INVALID
+
+
 def test_tiny_textures_and_coordinates_beyond_the_edges(orc):
     """Clamp to edge (the sampler of src/renderer/drawer.rs:231) where it matters most: textures of
     one texel, one row or one column, odd sizes, and texture coordinates far outside [0, 1], so that

@@ -241,3 +241,46 @@ def test_ui_quads_follow_the_reference_layout(orc):
     # the second child is drawn later at the same depth: where they overlap the first one stays (Less)
     both = (xs.min() <= 70) and prim[70, 60] in (0, 1)
     assert both
+
+
+def test_lit_shading_known_answers(orc):
+    """The lighting extension (no reference counterpart; defined at sxe_set_light in include/sxe.h):
+    closed forms for a quad in the plane z = 0.5 of clip space, whose face normal is +z or -z."""
+    from renderer_amd import api
+    tex = np.zeros((4, 4, 4), np.uint8)
+    tex[...] = [200, 100, 50, 255]
+    scene = soup_scene(quad(2, 2, 30, 30, 32), textures=[tex], width=32, height=32)
+    f32 = np.float32
+
+    def expect(a, s):
+        return [orc.srgb_encode(float(f32(f32(orc.srgb_decode(c)) * f32(a)) + f32(s))) for c in (200, 100, 50)] + [255]
+
+    def lit(**light):
+        r = render(orc, scene, shading=orc.SHADE_LIT, light=light)
+        cov = r["prim"] != EMPTY
+        assert cov.sum() == 28 * 28 and (r["color"][~cov] == [218, 124, 0, 255]).all()
+        colours = np.unique(r["color"][cov].reshape(-1, 4), axis=0)
+        assert len(colours) == 1  # flat: one colour per triangle, and both triangles lie in one plane
+        return colours[0].tolist()
+
+    # light and viewer on the normal: n.l = n.h = 1, so a = ambient + diffuse and s = specular
+    base = dict(to_viewer=(0, 0, 1), ambient=0.25, diffuse=0.5, specular=0.125, shininess_log2=4)
+    assert lit(to_light=(0, 0, 3), **base) == expect(0.75, 0.125)
+    # the face is lit from whichever side the viewer is on
+    assert lit(to_light=(0, 0, -2), **dict(base, to_viewer=(0, 0, -1))) == expect(0.75, 0.125)
+    # light behind the face as the viewer sees it: ambient only
+    assert lit(to_light=(0, 0, -1), **base) == expect(0.25, 0.0)
+    # 60 degrees off the normal: n.l = 1/2 in exact arithmetic; n.h = cos 30, raised to the 16th
+    l, v, h = api.light_vectors(api.make_light(to_light=(0.0, np.sqrt(3.0), 1.0), to_viewer=(0, 0, 1)))
+    assert abs(float(l[2]) - 0.5) < 1e-6 and abs(float(h[2]) - np.cos(np.pi / 6)) < 1e-6 and v.tolist() == [0, 0, 1]
+    ndl, spec = f32(l[2]), f32(h[2])
+    for _ in range(4):
+        spec = f32(spec * spec)
+    assert lit(to_light=(0.0, float(np.sqrt(3.0)), 1.0), **base) == expect(f32(0.25) + f32(0.5) * ndl, f32(0.125) * spec)
+    # a light the oracle refuses as the library does
+    with pytest.raises(ValueError):
+        render(orc, scene, shading=orc.SHADE_LIT, light=dict(to_light=(0, 0, 0)))
+    with pytest.raises(api.SxeError):
+        api.light_vectors(api.make_light(to_viewer=(0, float("nan"), 0)))
+    with pytest.raises(api.SxeError):
+        api.light_vectors(api.make_light(shininess_log2=17))

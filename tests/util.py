@@ -19,7 +19,7 @@ def render_oracle(orc, scene, width=None, height=None, models=None, view=None, p
 
 
 def render_hip(scene, width=None, height=None, models=None, view=None, proj=None, shading=0, scissor=None,
-               want_clip=False, use_drawables=False, image=0):
+               want_clip=False, use_drawables=False, image=0, light=None):
     width = width or scene.size[0]
     height = height or scene.size[1]
     with api.HipDrawer(width, height, coverage=True, shading=shading, scissor=scissor) as d:
@@ -28,6 +28,8 @@ def render_hip(scene, width=None, height=None, models=None, view=None, proj=None
             d.update_drawables(scene.drawables())
         else:
             d.update_scene(scene)
+        if light is not None:
+            d.set_light(**light)
         if models is not None:
             d.update_uniforms(models)
         if view is not None:

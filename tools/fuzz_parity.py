@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: many random scenes, HIP frame against the oracle's, bit for bit (colour, depth,
-primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode,
+primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode (the lit extension under random lights among them),
 random scissor band, several objects and textures; sphere fields under random cameras.
 
   fuzz_parity.py [cases] [seed]
@@ -26,7 +26,7 @@ def run(cases, seed0, verbose=True):
 
 def one_case(seed, case, verbose):
     rng = np.random.default_rng(seed)
-    shading = int(rng.integers(0, 3))
+    shading = int(rng.integers(0, 4))
     if case % 3 == 2:
         s = scenes.config_scene(int(rng.choice([2, 3, 5])), scale=float(rng.uniform(0.03, 0.12)))
         w, h = s.size
@@ -56,8 +56,12 @@ def one_case(seed, case, verbose):
         a, b = sorted(rng.integers(0, h + 1, 2).tolist())
         if b > a:
             scissor = (a, b)
-    ref = oracle.render(s, models, view, proj, w, h, shading=shading, scissor=scissor, threads=8)
-    got = render_hip(s, models=models, view=view, proj=proj, shading=shading, scissor=scissor)
+    light = None
+    if shading == 3 and rng.random() < 0.7:  # (the lit extension: else under the default light)
+        light = dict(to_light=rng.normal(size=3).tolist(), to_viewer=rng.normal(size=3).tolist(), ambient=float(rng.uniform(0, 0.5)),
+                     diffuse=float(rng.uniform(0, 1.2)), specular=float(rng.uniform(0, 1)), shininess_log2=int(rng.integers(0, 9)))
+    ref = oracle.render(s, models, view, proj, w, h, shading=shading, scissor=scissor, threads=8, light=light)
+    got = render_hip(s, models=models, view=view, proj=proj, shading=shading, scissor=scissor, light=light)
     y0, y1 = scissor if scissor else (0, h)
     ok = (np.array_equal(ref["color"][y0:y1], got["color"][y0:y1]) and
           np.array_equal(ref["depth"][y0:y1].view(np.uint32), got["depth"][y0:y1].view(np.uint32)) and
