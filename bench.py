@@ -12,7 +12,10 @@ N > 1 (one process per GPU, launched by torch.distributed.run):
   sortfirst  (default) each frame is cut into N bands of whole tile rows; geometry is replicated;
              the finished bands are gathered on rank 0 over RCCL (grouped send/receive, every band
              at its own size) while the next frame is being drawn.  One step = 1 frame.  Strong
-             scaling: the metric BASELINE.json names.
+             scaling: the metric BASELINE.json names.  Before the warm-up the ranks time the
+             drawing of equal bands and their gather on their own; when the gather is the slower
+             of the two (few ranks: each band is a large share of the frame over one link), rank 0,
+             which sends nothing, takes a taller band (--bands even: equal bands).
   frames     frame-parallel: rank r renders animation frames r, r+N, ...; every rank advances the
              replicated rotation state through all frames; no data-path collective.  One step = N
              frames.  Weak scaling.
@@ -114,6 +117,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the last frame with the oracle (slow)")
+    ap.add_argument("--bands", choices=["auto", "even"], default="auto",
+                    help="sortfirst: band heights evened out against the measured gather (auto) or equal")
     ap.add_argument("--pipeline", action="store_true",
                     help="with one GPU: go through the sort-first gather pipeline anyway (its band is the whole frame)")
     args = ap.parse_args()
@@ -154,12 +159,58 @@ def main():
     if sortfirst and scissor[1] <= scissor[0]:
         sys.exit("rank %d has no tile row to render (%d ranks for %d rows)" % (rank, world, height))
 
-    drawer = api.HipDrawer(width, height, device=local_rank, n_images=2, scissor=scissor, timing=True)
-    drawer.update_scene(scene)
-    drawer.update_camera(scene.camera)
-    pipe = shard.SortFirstPipeline(drawer, height, width, world, rank) if sortfirst else None
+    def make_drawer(band):
+        d = api.HipDrawer(width, height, device=local_rank, n_images=2, scissor=band, timing=True)
+        d.update_scene(scene)
+        d.update_camera(scene.camera)
+        return d
 
-    frame_no = [0]
+    drawer = make_drawer(scissor)
+    weights, tuning, first_frame = None, None, 0
+    if sortfirst and world > 1 and args.bands == "auto":
+        # Equal bands first: what a frame costs this rank apart from its rows (geometry stage,
+        # replicated), what its rows cost, and what the gather of equal bands costs on its own.
+        for i in range(12):
+            if i == 4:
+                drawer.sync()
+                drawer.reset_timing_totals()
+            drawer.rotation_system(SEED, i, DELTA_MS)
+            drawer.draw(i & 1)
+        drawer.sync()
+        acc, frames = drawer.timing_totals()
+        share = (scissor[1] - scissor[0]) / float(height)
+        fixed_ms = (acc["object_ms"] + acc["setup_ms"] + acc["finish_ms"]) / max(frames, 1)
+        band_ms = acc["raster_shade_ms"] / max(frames, 1) / share
+        band = shard.band_tensor(drawer, 0, scissor[0], scissor[1])
+        landing = torch.empty((height, width, 4), dtype=torch.uint8, device=band.device) if rank == 0 else None
+        for k in range(8):
+            if k == 3:
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_g = time.perf_counter()
+            shard.gather_bands(band, height, width, world, rank, out=landing)
+        torch.cuda.synchronize()
+        dist.barrier()
+        link_ms = 1e3 * (time.perf_counter() - t_g) / 5.0 * world  # (a whole frame over one link)
+        del band, landing
+        agreed = torch.tensor([fixed_ms, band_ms, link_ms], dtype=torch.float64, device=stat_device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MAX)
+        fixed_ms, band_ms, link_ms = [float(x) for x in agreed.tolist()]
+        weights = shard.balanced_weights(world, 0, fixed_ms, band_ms, link_ms)
+        tuning = {"fixed_ms": fixed_ms, "band_ms_per_frame_of_rows": band_ms, "gather_ms_per_frame_over_one_link": link_ms,
+                  "weights": weights}
+        if len(set(weights)) == 1:
+            weights = None
+        new_band = shard.band_rows(height, world, rank, weights=weights)
+        if new_band != scissor:
+            drawer.close()
+            scissor = new_band
+            drawer = make_drawer(scissor)
+        else:
+            first_frame = 12  # (the rotation system goes on where the trial frames left it)
+    pipe = shard.SortFirstPipeline(drawer, height, width, world, rank, weights=weights) if sortfirst else None
+
+    frame_no = [first_frame]
 
     def step(i):
         # ECS rotation update on the device, then the frame
@@ -288,6 +339,10 @@ def main():
         }
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
+        if sortfirst:
+            result["bands"] = shard.all_bands(height, world, weights=weights)
+        if tuning is not None:
+            result["band_tuning"] = tuning
         if per_rank is not None:
             result["per_rank"] = per_rank
         if args.scale != 1.0:

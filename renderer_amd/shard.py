@@ -14,21 +14,63 @@ import numpy as np
 TILE = 32
 
 
-def band_rows(height, world, rank, tile=TILE):
-    """Rows [y0, y1) of rank's band: contiguous, whole tile rows, sizes differing by at most one tile row."""
+def _tile_rows_per_rank(n_tile_rows, world, weights):
+    """Whole tile rows per rank in proportion to the weights (largest remainders first; a rank with
+    a positive weight keeps at least one row while there are rows to go round)."""
+    w = [max(float(x), 0.0) for x in weights]
+    if len(w) != world or not sum(w) > 0.0:
+        raise ValueError("weights must be %d non-negative numbers with a positive sum" % world)
+    ideal = [n_tile_rows * x / sum(w) for x in w]
+    rows = [int(x) for x in ideal]
+    by_remainder = sorted(range(world), key=lambda r: (-(ideal[r] - rows[r]), r))
+    for r in by_remainder[:n_tile_rows - sum(rows)]:
+        rows[r] += 1
+    for r in range(world):  # nobody with work to do is left without a row
+        if w[r] > 0.0 and rows[r] == 0 and max(rows) > 1:
+            rows[rows.index(max(rows))] -= 1
+            rows[r] = 1
+    return rows
+
+
+def band_rows(height, world, rank, tile=TILE, weights=None):
+    """Rows [y0, y1) of rank's band: contiguous, whole tile rows.  Without weights the bands differ
+    by at most one tile row; with weights (one number per rank) their heights are in that proportion."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank %r of %r" % (rank, world))
     n_tile_rows = (height + tile - 1) // tile
-    base, extra = divmod(n_tile_rows, world)
-    first = rank * base + min(rank, extra)
-    count = base + (1 if rank < extra else 0)
+    if weights is None:
+        base, extra = divmod(n_tile_rows, world)
+        first = rank * base + min(rank, extra)
+        count = base + (1 if rank < extra else 0)
+    else:
+        rows = _tile_rows_per_rank(n_tile_rows, world, weights)
+        first, count = sum(rows[:rank]), rows[rank]
     y0 = min(first * tile, height)
     y1 = min((first + count) * tile, height)
     return y0, y1
 
 
-def all_bands(height, world, tile=TILE):
-    return [band_rows(height, world, r, tile) for r in range(world)]
+def all_bands(height, world, tile=TILE, weights=None):
+    return [band_rows(height, world, r, tile, weights) for r in range(world)]
+
+
+def balanced_weights(world, dst, fixed_ms, band_ms, link_ms):
+    """Band weights for a sort-first split whose frames are gathered on `dst` while the next ones are
+    drawn.  A rank with share x of the rows needs fixed_ms + band_ms * x to draw its band (the
+    geometry stage is replicated, the tile stage follows the rows) and, unless it is `dst`,
+    link_ms * x to send it, every sender over a link of its own.  With equal bands and few ranks
+    the senders' links set the pace (two ranks: half a frame over one link); giving `dst`, which
+    sends nothing, a taller band s evens that out: fixed + band * s = link * (1 - s) / (world - 1).
+    Equal weights when drawing is the slower side anyway."""
+    even = [1.0] * world
+    if world < 2 or not (link_ms > 0.0 and band_ms >= 0.0 and fixed_ms >= 0.0):
+        return even
+    if link_ms / world <= fixed_ms + band_ms / world:
+        return even
+    per_sender = link_ms / (world - 1)
+    s = (per_sender - fixed_ms) / (band_ms + per_sender)
+    s = min(max(s, 1.0 / world), 0.9)
+    return [s if r == dst else (1.0 - s) / (world - 1) for r in range(world)]
 
 
 def views_for_rank(n_views, world, rank):
@@ -38,7 +80,7 @@ def views_for_rank(n_views, world, rank):
     return v0, v0 + base + (1 if rank < extra else 0)
 
 
-def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None):
+def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None, weights=None):
     """Collect every rank's finished band on rank `dst`: one send per rank, one receive per sender
     on `dst`, all posted as one group (on RCCL the receives then run concurrently, one xGMI link
     per sending GPU), every band at its own size, straight into its rows of the frame.
@@ -46,14 +88,15 @@ def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None):
     `band` is this rank's rows as a (rows, width, 4) uint8 torch tensor (a CUDA tensor for the
     nccl/RCCL backend, a CPU tensor for gloo).  On `dst` the frame is assembled in `out` (a
     (height, width, 4) uint8 tensor on the band's device; allocated when None) and returned;
-    other ranks return None.  Ranks whose band is empty take no part in the exchange.
+    other ranks return None.  Ranks whose band is empty take no part in the exchange.  `weights`:
+    the band heights' proportions, as for band_rows (every rank must pass the same).
     CUDA tensors on a gloo group (a rehearsal of several ranks on fewer GPUs) go through host
     memory: gloo does not send from device memory.
     """
     import torch
     import torch.distributed as dist
 
-    bands = all_bands(height, world)
+    bands = all_bands(height, world, weights=weights)
     y0, y1 = bands[rank]
     if tuple(band.shape) != (y1 - y0, width, 4) or band.dtype != torch.uint8:
         raise ValueError("band has shape %s, expected %s uint8" % (tuple(band.shape), (y1 - y0, width, 4)))
@@ -110,16 +153,18 @@ class SortFirstPipeline:
     into image i % 2 on the drawer's own stream while the band of frame i - 1 is being gathered on
     a second stream, ordered by events only (the host never waits inside the loop).
 
-    The drawer must have been created with this rank's scissor band and at least two images.
+    The drawer must have been created with this rank's scissor band (band_rows with the same
+    `weights`) and at least two images.
     Frames that overflow a work buffer are drawn again by the library when it takes their result,
     which is after their band was sent: call `drawer.sync()` and check `stats()["redraws"]` when
     that matters (it cannot happen once the buffers have grown to the scene).
     """
 
-    def __init__(self, drawer, height, width, world, rank, dst=0, group=None):
+    def __init__(self, drawer, height, width, world, rank, dst=0, group=None, weights=None):
         import torch
         self.d, self.h, self.w, self.world, self.rank, self.dst, self.group = drawer, height, width, world, rank, dst, group
-        self.y0, self.y1 = band_rows(height, world, rank)
+        self.weights = weights
+        self.y0, self.y1 = band_rows(height, world, rank, weights=weights)
         dev = torch.device("cuda", drawer.cfg.device)
         self.lib_stream = torch.cuda.ExternalStream(drawer.stream_ptr(), device=dev)
         self.side = torch.cuda.Stream(device=dev)
@@ -141,7 +186,7 @@ class SortFirstPipeline:
         self.side.wait_event(self.drawn[img])
         with torch.cuda.stream(self.side):
             self.gather_start[img].record(self.side)
-            gather_bands(self.bands[img], self.h, self.w, self.world, self.rank, self.dst, self.group, out=self.frame)
+            gather_bands(self.bands[img], self.h, self.w, self.world, self.rank, self.dst, self.group, out=self.frame, weights=self.weights)
             self.gathered[img].record(self.side)
         self.used[img] = True
 

@@ -34,3 +34,9 @@ def test_sort_first_bench_with_ranks_sharing_one_gpu(world, config):
     assert out["check"] == {"color_equal": True, "depth_equal": True}
     assert sum(r["rows"] for r in out["per_rank"]) == int({3: 2160, 4: 4320}[config] * 0.25)  # the bands cover the (scaled) frame
     assert all(r["raster_shade_ms"] > 0 for r in out["per_rank"])
+    # the band heights come out of the trial of equal bands before the warm-up (through host memory the
+    # gather is slow: rank 0, which sends nothing, ends up with the tallest band)
+    tune = out["band_tuning"]
+    assert tune["fixed_ms"] > 0 and tune["gather_ms_per_frame_over_one_link"] > 0 and len(tune["weights"]) == world
+    assert [b - a for a, b in out["bands"]] == [int(r["rows"]) for r in out["per_rank"]]
+    assert tune["weights"][0] >= max(tune["weights"][1:])
