@@ -21,6 +21,8 @@ def run(cases, seed0, verbose=True):
     bad = 0
     for case in range(cases):
         bad += 0 if one_case(seed0 * 1000 + case, case, verbose) else 1
+        if verbose and case % 500 == 499:
+            print("%d cases so far, %d mismatches" % (case + 1, bad), flush=True)  # (a long run must be seen to be alive)
     return bad
 
 
