@@ -569,6 +569,12 @@ def test_full_size_config2_against_oracle(orc):
     got = render_hip(s)
     assert (ref["prim"] != 0xFFFFFFFF).sum() > 100000
     assert_frames_equal(got, ref, what="config 2 full size")
+    # the same frame lit (the benchmark's configuration list calls this scene "Blinn-Phong + depth";
+    # the lit mode is this build's own extension, compared with the oracle's restatement of it)
+    ref_lit = render_oracle(orc, s, threads=16, shading=api.SHADE_LIT)
+    got_lit = render_hip(s, shading=api.SHADE_LIT)
+    assert_frames_equal(got_lit, ref_lit, what="config 2 full size, lit")
+    assert np.array_equal(ref_lit["depth"], ref["depth"]) and not np.array_equal(ref_lit["color"], ref["color"])
 
 
 def test_full_size_config4_single_context_and_eight_bands(orc):
