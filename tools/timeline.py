@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from renderer_amd import api, scenes
-s = scenes.config_scene(3)
+s = scenes.config_scene(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 w, h = s.size
 with api.HipDrawer(w, h, timing=True, debug_flags=(1 << 26)) as d:
     d.update_scene(s); d.update_camera(s.camera)
