@@ -797,6 +797,12 @@ def test_translucent_textures_are_blended_in_submission_order(orc):
     ref = render_oracle(orc, s, threads=8)
     got = render_hip(s)
     assert_frames_equal(got, ref, what="spheres, two of four textures translucent")
+    # the build of the kernels that keeps no primitive-id image
+    with api.HipDrawer(*s.size) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        assert np.array_equal(d.read_color(0), ref["color"]) and np.array_equal(d.read_depth(0).view(np.uint32), ref["depth"].view(np.uint32))
     for shading in (1, 2):
         ref = render_oracle(orc, s, shading=shading)
         got = render_hip(s, shading=shading)
