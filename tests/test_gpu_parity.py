@@ -751,6 +751,55 @@ def test_more_than_2_to_the_32_bin_entries_is_a_capacity_error():
         assert (d.read_depth(0) < 1.0).all()
 
 
+_THREADS_CHILD = r"""
+import sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from renderer_amd import api, scenes
+from oracle import oracle
+oracle.build(); oracle.lib()
+jobs = [scenes.config_scene(2, scale=0.15 + 0.05 * k) for k in range(6)]
+go = threading.Barrier(len(jobs))
+got, errors = [None] * len(jobs), []
+def work(k):
+    try:
+        s = jobs[k]
+        w, h = s.size
+        go.wait()  # every thread creates its context and draws its first frame at the same moment
+        with api.HipDrawer(w, h, coverage=True) as d:
+            d.update_scene(s); d.update_camera(s.camera)
+            for frame in range(3):
+                d.rotation_system(7 + k, frame, 16.0)
+                d.draw(0)
+            got[k] = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0), "t": d.read_transforms()}
+    except Exception as e:  # (reported by the main thread)
+        errors.append("thread %d: %r" % (k, e))
+threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+[t.start() for t in threads]; [t.join() for t in threads]
+assert not errors, errors
+for k, s in enumerate(jobs):
+    w, h = s.size
+    ref = oracle.render(s, oracle.to_model(got[k]["t"]), *oracle.camera(s.camera, w, h), w, h, threads=4)
+    for plane in ("color", "prim"):
+        assert np.array_equal(ref[plane], got[k][plane]), "thread %d: %s differs" % (k, plane)
+    assert np.array_equal(ref["depth"].view(np.uint32), got[k]["depth"].view(np.uint32)), "thread %d: depth differs" % k
+print("threads-ok")
+"""
+
+
+def test_contexts_created_and_driven_from_different_threads(orc):
+    """sxe.h: distinct contexts are independent and may be driven from different threads.  Six
+    threads of a fresh process (so that the once-per-device set-up -- lookup tables, the static work
+    array's address -- happens under contention) create a context each at the same moment, draw
+    three frames of their own scene and must all get the oracle's frame."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _THREADS_CHILD, root], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "threads-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_sort_first_pipeline_on_one_rank(orc):
     """The overlapped draw/gather loop of shard.SortFirstPipeline with a single rank (its band is the
     whole frame, the gather a device copy): events between the library's stream and the gather
