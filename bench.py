@@ -19,6 +19,8 @@ N > 1 (one process per GPU, launched by torch.distributed.run):
   frames     frame-parallel: rank r renders animation frames r, r+N, ...; every rank advances the
              replicated rotation state through all frames; no data-path collective.  One step = N
              frames.  Weak scaling.
+             (A sortfirst run measures this split as well, briefly, after the headline figure, and
+             reports it under the key "frame_parallel".)
 
 Prints ONE JSON line on rank 0.
 """
@@ -361,6 +363,44 @@ def main():
             result["check"] = {"color_equal": bool(np.array_equal(ref["color"], got)),
                                "depth_equal": bool(np.array_equal(ref["depth"][y0:y1].view(np.uint32), depth[y0:y1].view(np.uint32)))}
     drawer.close()
+    if sortfirst and world > 1:
+        # The other split as a second key: every rank draws whole frames of its own (frames r, r + N,
+        # ...), no exchange, weak scaling.  After the headline measurement, on a context of its own.
+        del pipe
+        fp_steps, fp_warmup = max(8, min(args.steps, 50)), 3
+        d2 = api.HipDrawer(width, height, device=local_rank, n_images=2)
+        d2.update_scene(scene)
+        d2.update_camera(scene.camera)
+        done = 0  # frames of the animation whose rotation update this rank has applied
+
+        def frame_step(i):
+            nonlocal done
+            target = i * world + rank
+            if done <= target:
+                d2.rotation_system(SEED, done, DELTA_MS, n_frames=target - done + 1)
+                done = target + 1
+            d2.draw(i & 1)
+
+        for i in range(fp_warmup):
+            frame_step(i)
+        d2.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(fp_steps):
+            frame_step(fp_warmup + i)
+        d2.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=stat_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d2.close()
+        if rank == 0:
+            fp_elapsed = float(t.item())
+            result["frame_parallel"] = {"value": n_prims * fp_steps * world / fp_elapsed, "unit": "triangles/s", "scaling": "weak",
+                                        "steps": fp_steps, "warmup": fp_warmup, "frames_per_step": world,
+                                        "ms_per_step": 1e3 * fp_elapsed / fp_steps,
+                                        "parallelism": "frame-parallel%d, no exchange" % world}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,3 +40,6 @@ def test_sort_first_bench_with_ranks_sharing_one_gpu(world, config):
     assert tune["fixed_ms"] > 0 and tune["gather_ms_per_frame_over_one_link"] > 0 and len(tune["weights"]) == world
     assert [b - a for a, b in out["bands"]] == [int(r["rows"]) for r in out["per_rank"]]
     assert tune["weights"][0] >= max(tune["weights"][1:])
+    # the frame-parallel split is measured as a second key
+    fp = out["frame_parallel"]
+    assert fp["scaling"] == "weak" and fp["frames_per_step"] == world and fp["value"] > 0
