@@ -371,22 +371,36 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
     r.x0 = (int32_t)w.geo.x; r.y0 = (int32_t)w.geo.y; r.d1 = w.geo.z; r.d2 = w.geo.w;
     r.z0 = r.dz1 = r.dz2 = r.rA = 0.0f; // (the depth plane is not needed any more; the area comes with h)
     if (h.tex_fan >> 24) {
-        // a clipped triangle won: exactly one triangle of its fan covers this sample
+        // A clipped triangle won: which triangle of its fan?  As a rule one of them covers the
+        // sample, but the fan's corners are snapped to the grid one by one, and two of its
+        // triangles can overlap by a sliver there.  Drawn one after the other under
+        // Comparison::Less, the first of those with the smallest depth is the one that stays, and
+        // that depth is the pixel's: the first covering triangle whose depth plane gives exactly
+        // the winning depth is taken (the first covering one, should none do so).
         const long long sx = 256 * px + 128, sy = 256 * py + 128;
         const uint32_t fan_base = h.fan_or_ra, n_fan = h.tex_fan >> 24;
+        bool covered = false;
         for (uint32_t f = 0; f < n_fan; ++f) {
             const RastRec fr = a.rast[fan_base + f];
             if (fr.x0 == kNoRaster) continue;
             const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
             const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
                             fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
+            const long long R1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2), R2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0);
             const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
-            const long long E1 = fx1 * (sy - ft.y2) - fy1 * (sx - ft.x2) - edge_bias((int32_t)fx1, (int32_t)fy1);
-            const long long E2 = fx2 * (sy - ft.y0) - fy2 * (sx - ft.x0) - edge_bias((int32_t)fx2, (int32_t)fy2);
+            const long long E1 = R1 - edge_bias((int32_t)fx1, (int32_t)fy1);
+            const long long E2 = R2 - edge_bias((int32_t)fx2, (int32_t)fy2);
             if ((E0 | E1 | E2) >= 0) {
-                slot = fan_base + f;
-                r = fr;
-                break;
+                // the depth the raster pass gave this triangle's fragment (raster_lane, raster_wide)
+                const float fl1 = (float)R1 * fr.rA, fl2 = (float)R2 * fr.rA;
+                const float fz = clamp_depth((fr.z0 + fl1 * fr.dz1) + fl2 * fr.dz2);
+                const bool is_winner = __float_as_uint(fz) == __float_as_uint(w.depth);
+                if (!covered || is_winner) {
+                    slot = fan_base + f;
+                    r = fr;
+                    covered = true;
+                }
+                if (is_winner) break;
             }
         }
         h = a.shade[slot];

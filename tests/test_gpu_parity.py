@@ -58,6 +58,41 @@ def test_triangle_soups(orc, seed):
     assert_frames_equal(got, ref, what="soup seed %d" % seed)
 
 
+def test_fan_triangles_that_overlap_by_a_sliver(orc):
+    """A triangle cut by the near and the far plane: the corners of its fan are snapped to the grid
+    one by one, and at pixel (33, 51) of this frame two of the fan's triangles both cover the
+    sample.  Drawn in turn under Less, the one with the smaller depth stays, and its attribute
+    planes, not those of the first one that covers, must shade the pixel (found by
+    tools/fuzz_parity.py: one pixel of one scene in twelve thousand)."""
+    from tests.util import soup_scene
+    tri = np.array([[[0.55813956, -0.48756218, -0.02677643], [0.5810299, -0.33630487, 0.6650742],
+                     [0.49605954, -0.896145, 1.0457937]]], dtype=np.float32)
+    uv = np.array([[0.04350607, -0.09129993], [0.7519953, 1.4499753], [-0.29209238, 0.08491877]], dtype=np.float32)
+    rng = np.random.default_rng(5)
+    colors = rng.uniform(0, 1, (3, 3))
+    tex = rng.integers(0, 256, size=(17, 23, 4), dtype=np.uint8)
+    for translucent in (False, True):
+        t = tex.copy()
+        if not translucent:
+            t[..., 3] = 255
+        s = soup_scene(tri, uvs=uv, colors=colors, textures=[t], width=43, height=201)
+        for shading in (0, 1, 2, 3):
+            ref, got = _soup_pair(orc, s, shading=shading)
+            assert ref["stats"]["prims_clipped"] == 1 and ref["prim"][51, 33] == 0
+            assert_frames_equal(got, ref, what="overlapping fan triangles, shading %d%s" % (shading, ", translucent" if translucent else ""))
+    # the same sliver among a crowd of clipped triangles: random triangles through both planes
+    n = 3000
+    tris = np.zeros((n, 3, 3), np.float32)
+    c = rng.uniform(-0.9, 0.9, (n, 1, 2))
+    tris[..., :2] = c + rng.uniform(-0.5, 0.5, (n, 3, 2))
+    tris[..., 2] = rng.uniform(-0.6, 1.6, (n, 3))
+    s = soup_scene(tris, uvs=rng.uniform(-0.5, 1.5, (3 * n, 2)), colors=rng.uniform(0, 1, (3 * n, 3)), textures=[tex | np.uint8(0)], width=211, height=173)
+    s.textures[0][..., 3] = 255
+    ref, got = _soup_pair(orc, s, shading=2)
+    assert ref["stats"]["prims_clipped"] > 1000
+    assert_frames_equal(got, ref, what="crowd of triangles through both planes")
+
+
 def test_micro_triangles_dense(orc):
     """Many sub-pixel triangles in few tiles: stresses the bin allocation and depth ties."""
     from tests.util import soup_scene
