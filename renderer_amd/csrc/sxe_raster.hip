@@ -375,14 +375,18 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
         // sample, but the fan's corners are snapped to the grid one by one, and two of its
         // triangles can overlap by a sliver there.  Drawn one after the other under
         // Comparison::Less, the first of those with the smallest depth is the one that stays, and
-        // that depth is the pixel's: the first covering triangle whose depth plane gives exactly
-        // the winning depth is taken (the first covering one, should none do so).
+        // that depth is the pixel's (the raster pass took the minimum over all of them): the first
+        // covering triangle whose depth plane gives exactly the winning depth is taken.
         const long long sx = 256 * px + 128, sy = 256 * py + 128;
         const uint32_t fan_base = h.fan_or_ra, n_fan = h.tex_fan >> 24;
-        bool covered = false;
         for (uint32_t f = 0; f < n_fan; ++f) {
-            const RastRec fr = a.rast[fan_base + f];
-            if (fr.x0 == kNoRaster) continue;
+            // (the record's halves one after the other, the depth plane only for a triangle that
+            // covers: the whole record held through the loop costs the shading of every pixel registers)
+            const uint4 fg = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)(fan_base + f)];
+            if ((int32_t)fg.x == kNoRaster) continue;
+            RastRec fr;
+            fr.x0 = (int32_t)fg.x; fr.y0 = (int32_t)fg.y; fr.d1 = fg.z; fr.d2 = fg.w;
+            fr.z0 = fr.dz1 = fr.dz2 = fr.rA = 0.0f;
             const Tri ft = unpack_tri(fr, a.wide, fan_base + f);
             const long long fx0 = ft.x2 - ft.x1, fy0 = ft.y2 - ft.y1, fx1 = ft.x0 - ft.x2, fy1 = ft.y0 - ft.y2,
                             fx2 = ft.x1 - ft.x0, fy2 = ft.y1 - ft.y0;
@@ -390,17 +394,15 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
             const long long E0 = fx0 * (sy - ft.y1) - fy0 * (sx - ft.x1) - edge_bias((int32_t)fx0, (int32_t)fy0);
             const long long E1 = R1 - edge_bias((int32_t)fx1, (int32_t)fy1);
             const long long E2 = R2 - edge_bias((int32_t)fx2, (int32_t)fy2);
-            if ((E0 | E1 | E2) >= 0) {
-                // the depth the raster pass gave this triangle's fragment (raster_lane, raster_wide)
-                const float fl1 = (float)R1 * fr.rA, fl2 = (float)R2 * fr.rA;
-                const float fz = clamp_depth((fr.z0 + fl1 * fr.dz1) + fl2 * fr.dz2);
-                const bool is_winner = __float_as_uint(fz) == __float_as_uint(w.depth);
-                if (!covered || is_winner) {
-                    slot = fan_base + f;
-                    r = fr;
-                    covered = true;
-                }
-                if (is_winner) break;
+            if ((E0 | E1 | E2) < 0) continue;
+            // (the depth the raster pass gave this triangle's fragment: raster_lane, raster_wide)
+            const uint4 fp = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)(fan_base + f) + 1]; // z0, dz1, dz2, rA
+            const float fl1 = (float)R1 * __uint_as_float(fp.w), fl2 = (float)R2 * __uint_as_float(fp.w);
+            const float fz = clamp_depth((__uint_as_float(fp.x) + fl1 * __uint_as_float(fp.y)) + fl2 * __uint_as_float(fp.z));
+            if (__float_as_uint(fz) == __float_as_uint(w.depth)) {
+                slot = fan_base + f;
+                r = fr;
+                break;
             }
         }
         h = a.shade[slot];
