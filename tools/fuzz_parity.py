@@ -43,6 +43,16 @@ def one_case(seed, case, verbose):
         split = np.diff(np.sort(np.concatenate([[0, n], rng.integers(0, n + 1, n_obj - 1)]))).tolist()
         split = [k for k in split if k > 0]
         tris = random_soup(rng, n, w, h)
+        if rng.random() < 0.3:
+            # corners on a quarter-pixel grid and a few distinct depths: samples that lie exactly on
+            # edges and corners (the top-left rule), exact depth ties, shared edges
+            q = float(rng.choice([1.0, 2.0, 4.0]))
+            px = np.round((tris[..., 0] + 1.0) * 0.5 * w * q) / q
+            py = np.round((tris[..., 1] + 1.0) * 0.5 * h * q) / q
+            on = np.abs(tris[..., :2]).max(axis=(1, 2)) < 1.4  # (the huge and the off-screen ones stay as they are)
+            tris[on, :, 0] = (2.0 * px / w - 1.0)[on]
+            tris[on, :, 1] = (2.0 * py / h - 1.0)[on]
+            tris[..., 2] = np.round(tris[..., 2] * 16.0) / 16.0
         texs = [rng.integers(0, 256, size=(int(rng.integers(1, 40)), int(rng.integers(1, 40)), 4), dtype=np.uint8) for _ in range(3)]
         translucent = rng.random() < 0.25  # then the tiles take the ordered (blending) path
         for k, t in enumerate(texs):
