@@ -3,7 +3,7 @@
 primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode (the lit extension under random lights among them),
 random scissor band, several objects and textures; sphere fields under random cameras.
 
-  fuzz_parity.py [cases] [seed]
+  fuzz_parity.py [cases] [seed]          (FUZZ_BIG=1: the soups' frames seven times as wide and high)
 """
 import sys, os, time
 import numpy as np
@@ -13,6 +13,9 @@ from oracle import oracle
 from renderer_amd import api, scenes
 from tests.util import random_soup, soup_scene, render_hip, IDENT
 
+
+
+BIG = os.environ.get("FUZZ_BIG", "") == "1"
 
 
 def run(cases, seed0, verbose=True):
@@ -38,6 +41,8 @@ def one_case(seed, case, verbose):
         desc = "%s %dx%d" % (s.name, w, h)
     else:
         w, h = int(rng.integers(9, 400)), int(rng.integers(9, 300))
+        if BIG:  # frames of up to 2800 x 2100: thousands of tiles, triangles over hundreds of them
+            w, h = 7 * w, 7 * h
         n = int(rng.integers(1, 1500))
         n_obj = int(rng.integers(1, 6))
         split = np.diff(np.sort(np.concatenate([[0, n], rng.integers(0, n + 1, n_obj - 1)]))).tolist()
