@@ -66,6 +66,14 @@ def main():
     m = oracle.to_model(s.transforms)
     v, p = oracle.camera(s.camera, 96, 72)
     save("blend_cube_96x72.npz", s, m, v, p, oracle.render(s, m, v, p, 96, 72))
+    # 6. one triangle through the near and the far plane whose fan triangles, snapped corner by corner,
+    # overlap by a sliver at pixel (33, 51): the later fan triangle has the smaller depth there and stays
+    tri = np.array([[[0.55813956, -0.48756218, -0.02677643], [0.5810299, -0.33630487, 0.6650742],
+                     [0.49605954, -0.896145, 1.0457937]]], dtype=np.float32)
+    uv = np.array([[0.04350607, -0.09129993], [0.7519953, 1.4499753], [-0.29209238, 0.08491877]], dtype=np.float32)
+    s = soup_scene(tri, uvs=uv, textures=[scenes.checker_texture(16, 3)], width=43, height=201)
+    m = np.tile(IDENT, (1, 1))
+    save("sliver_soup_43x201.npz", s, m, IDENT, IDENT, oracle.render(s, m, IDENT, IDENT, 43, 201))
 
 
 if __name__ == "__main__":
