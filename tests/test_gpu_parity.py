@@ -93,6 +93,26 @@ def test_fan_triangles_that_overlap_by_a_sliver(orc):
     assert_frames_equal(got, ref, what="crowd of triangles through both planes")
 
 
+def test_more_textures_than_the_tile_kernel_keeps_in_lds(orc):
+    """The tile kernel keeps the descriptors of up to 64 textures in LDS; a longer table is read
+    from memory (a build of the kernel of its own).  Ninety objects with a texture each, opaque
+    and with some translucent ones, in every shading mode that samples a texture."""
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(64)
+    n_obj, per = 90, 12
+    texs = [rng.integers(0, 256, size=(int(rng.integers(1, 20)), int(rng.integers(1, 20)), 4), dtype=np.uint8) for _ in range(n_obj)]
+    for translucent in (False, True):
+        for k, t in enumerate(texs):
+            t[..., 3] = rng.integers(0, 256, size=t.shape[:2], dtype=np.uint8) if (translucent and k % 7 == 0) else 255
+        n = n_obj * per
+        s = soup_scene(random_soup(rng, n, 150, 110, kinds=("small", "medium", "large", "near")), uvs=rng.uniform(-0.2, 1.2, (3 * n, 2)),
+                       colors=rng.uniform(0, 1, (3 * n, 3)), textures=texs, width=150, height=110, objects_split=[per] * n_obj,
+                       tex_ids=rng.permutation(n_obj))
+        for shading in (0, 2, 3):
+            ref, got = _soup_pair(orc, s, shading=shading)
+            assert_frames_equal(got, ref, what="90 textures, shading %d%s" % (shading, ", some translucent" if translucent else ""))
+
+
 def test_micro_triangles_dense(orc):
     """Many sub-pixel triangles in few tiles: stresses the bin allocation and depth ties."""
     from tests.util import soup_scene
