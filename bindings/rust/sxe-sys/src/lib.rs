@@ -16,6 +16,8 @@ pub const SXE_SHADE_LIT: u32 = 3;
 
 pub const SXE_FLAG_WRITE_COVERAGE: u32 = 1;
 pub const SXE_FLAG_TIMING: u32 = 2;
+/// The draw list as the reference binary records it, indexing flaws included (src/renderer/drawer.rs:313-347).
+pub const SXE_FLAG_COMPAT_REFERENCE_INDEXING: u32 = 4;
 
 #[repr(C)]
 pub struct sxe_ctx {

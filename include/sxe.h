@@ -41,6 +41,20 @@ extern "C" {
 
 #define SXE_FLAG_WRITE_COVERAGE 1u /* keep a per-pixel primitive-id buffer (parity tests) */
 #define SXE_FLAG_TIMING 2u         /* bracket every kernel with HIP events (sxe_get_timings) */
+/* Build the draw list exactly as the reference binary records its command buffer
+ * (src/renderer/drawer.rs:313-347), three indexing flaws included:
+ *   1. inside a texture group the i-th mesh (unrendered ones counted) is drawn with the i-th model
+ *      matrix of the whole scene (dynamic offset i * stride, :326,331), not with its own;
+ *   2. its index range starts where the ranges of the draws recorded before it, in group order,
+ *      end (:313,345-346), although the index buffer is laid out in drawable order (:181-193);
+ *   3. an unrendered mesh does not move that cursor (:327-329).
+ * Scenes with one texture group and every mesh rendered come out the same either way.  Without
+ * the flag (the default) every rendered object draws its own mesh under its own matrix, which is
+ * what the reference means; with it, the images are the ones the reference binary produces for
+ * the same drawables, e.g. for its own demo world of 64 cubes over 3 textures (src/main.rs:201-227).
+ * Every object then needs a valid texture index, rendered or not (it takes a place in its group).
+ * sxe_read_clip_positions is not affected: it reports every drawable's vertices under its own matrix. */
+#define SXE_FLAG_COMPAT_REFERENCE_INDEXING 4u
 
 #define SXE_MAX_DIM 8192u          /* width and height limit (8K frames fit) */
 #define SXE_MAX_PRIMS (1u << 29)   /* triangles per frame */

@@ -600,7 +600,7 @@ static int validate(const orc_config *cfg, const orc_mesh *meshes, uint32_t n_me
     }
     for (uint32_t o = 0; o < n_objects; ++o) {
         if (objects[o].mesh >= n_meshes) return -1;
-        if (cfg->shading != ORC_SHADE_VERTEX_COLOR && objects[o].rendered &&
+        if (cfg->shading != ORC_SHADE_VERTEX_COLOR && (objects[o].rendered || (cfg->flags & ORC_FLAG_REFERENCE_INDEXING)) &&
             (objects[o].texture < 0 || (uint32_t)objects[o].texture >= n_textures)) return -1;
     }
     for (uint32_t t = 0; t < n_textures; ++t)
@@ -608,31 +608,60 @@ static int validate(const orc_config *cfg, const orc_mesh *meshes, uint32_t n_me
     return 0;
 }
 
-/* Draw order of update_drawables + generate_cmd_buffers (src/renderer/drawer.rs:481-487,315-347):
- * texture groups ascending, drawable order inside a group; every object uses its own model
- * matrix (the reference's group-local index is a defect this build does not reproduce). */
-static uint32_t *draw_order(const orc_object *objects, uint32_t n)
+/* One recorded draw_indexed (src/renderer/drawer.rs:345): a range of the index buffer, which holds
+ * the drawables' indices one after the other in caller order, rebased (src/renderer/drawer.rs:181-193),
+ * the model matrix bound at that moment (:331-341) and the group's texture (:319-324). */
+typedef struct {
+    uint64_t first_index;
+    uint32_t n_indices;
+    uint32_t matrix;
+    int32_t texture;
+} draw_cmd;
+
+/* The draws of update_drawables + generate_cmd_buffers (src/renderer/drawer.rs:481-487,313-347):
+ * texture groups ascending, drawable order inside a group, unrendered meshes skipped.
+ * cat_off[o] is where drawable o's indices start in the index buffer.
+ * Default: every object draws its own index range under its own model matrix -- what the
+ * reference means.  ORC_FLAG_REFERENCE_INDEXING: what it records: the matrix index is the mesh's
+ * position inside its texture group (`i` of `enumerate`, :326,331, unrendered meshes counted), the
+ * index range starts at a cursor that only advances by the draws recorded so far, in group order
+ * (:313,345-346), and an unrendered mesh leaves the cursor where it is (:327-329). */
+static draw_cmd *draw_list(const orc_config *cfg, const orc_mesh *meshes, const orc_object *objects, uint32_t n,
+                           const uint64_t *cat_off, uint32_t *n_draws)
 {
-    uint32_t *order = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
-    uint32_t m = 0;
-    int32_t lo = 0x7fffffff, hi = -0x7fffffff - 1;
-    for (uint32_t o = 0; o < n; ++o) {
-        if (objects[o].texture < lo) lo = objects[o].texture;
-        if (objects[o].texture > hi) hi = objects[o].texture;
-    }
-    /* stable: repeated passes over the distinct texture ids in ascending order */
-    int32_t cur = lo;
-    while (m < n) {
+    draw_cmd *draws = (draw_cmd *)malloc((size_t)(n ? n : 1) * sizeof(draw_cmd));
+    uint32_t m = 0, seen = 0;
+    uint64_t cursor = 0; /* current_mesh_index, :313 */
+    int compat = (cfg->flags & ORC_FLAG_REFERENCE_INDEXING) != 0;
+    int32_t cur = 0x7fffffff;
+    for (uint32_t o = 0; o < n; ++o)
+        if (objects[o].texture < cur) cur = objects[o].texture;
+    /* stable: one pass over the objects per distinct texture id, ascending */
+    while (seen < n) {
         int32_t next = 0x7fffffff;
+        uint32_t i = 0; /* position inside the group */
         for (uint32_t o = 0; o < n; ++o) {
-            if (objects[o].texture == cur) order[m++] = o;
-            else if (objects[o].texture > cur && objects[o].texture < next) next = objects[o].texture;
+            if (objects[o].texture == cur) {
+                ++seen;
+                if (objects[o].rendered) {
+                    uint32_t n_idx = meshes[objects[o].mesh].n_indices;
+                    draws[m].n_indices = n_idx;
+                    draws[m].texture = cur;
+                    draws[m].matrix = compat ? i : o;
+                    draws[m].first_index = compat ? cursor : cat_off[o];
+                    cursor += n_idx;
+                    ++m;
+                }
+                ++i;
+            } else if (objects[o].texture > cur && objects[o].texture < next) {
+                next = objects[o].texture;
+            }
         }
         if (next == 0x7fffffff) break;
         cur = next;
     }
-    (void)hi;
-    return order;
+    *n_draws = m;
+    return draws;
 }
 
 static int render_band(const orc_config *cfg, const orc_vertex *vertices, const uint32_t *indices,
@@ -676,27 +705,45 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
     }
 
     light_vectors light = make_light_vectors(cfg);
-    uint32_t *order = draw_order(objects, n_objects);
+    uint64_t *cat_off = (uint64_t *)malloc(((size_t)n_objects + 1) * sizeof(uint64_t));
+    cat_off[0] = 0;
+    for (uint32_t o = 0; o < n_objects; ++o) cat_off[o + 1] = cat_off[o] + meshes[objects[o].mesh].n_indices;
+    uint32_t n_draws = 0;
+    draw_cmd *draws = draw_list(cfg, meshes, objects, n_objects, cat_off, &n_draws);
     uint32_t prim_id = 0;
-    for (uint32_t d = 0; d < n_objects; ++d) {
-        uint32_t o = order[d];
-        if (!objects[o].rendered) continue;
-        const orc_mesh *m = &meshes[objects[o].mesh];
+    for (uint32_t d = 0; d < n_draws; ++d) {
+        const float *model = models + 16 * (size_t)draws[d].matrix;
         float pvm[16];
-        orc_mat4_mul(pv, models + 16 * (size_t)o, pvm);
-        for (uint32_t t = 0; t < m->n_indices / 3; ++t, ++prim_id) {
+        orc_mat4_mul(pv, model, pvm);
+        /* the drawable whose indices lie at the start of the range (binary search; then forwards) */
+        uint32_t k = 0;
+        {
+            uint32_t lo = 0, hi = n_objects;
+            while (hi - lo > 1) {
+                uint32_t mid = lo + (hi - lo) / 2;
+                if (cat_off[mid] <= draws[d].first_index) lo = mid; else hi = mid;
+            }
+            k = lo;
+        }
+        for (uint32_t t = 0; t < draws[d].n_indices / 3; ++t, ++prim_id) {
             cvert poly[12];
             float lit[2] = { 0.0f, 0.0f };
+            const orc_vertex *corner[3];
+            /* index fetch: position p of the index buffer belongs to drawable k, whose vertices the
+             * rebased index value selects from the vertex buffer (src/renderer/drawer.rs:173-193) */
+            uint64_t p = draws[d].first_index + 3 * (uint64_t)t;
+            while (p >= cat_off[k + 1]) ++k;
+            const orc_mesh *m = &meshes[objects[k].mesh];
+            for (int c = 0; c < 3; ++c)
+                corner[c] = &vertices[m->first_vertex + indices[m->first_index + (uint32_t)(p - cat_off[k]) + (uint32_t)c]];
             f.st.prims++;
             if (cfg->shading == ORC_SHADE_LIT)
-                light_terms(cfg, &light, models + 16 * (size_t)o, vertices[m->first_vertex + indices[m->first_index + 3 * t]].pos,
-                            vertices[m->first_vertex + indices[m->first_index + 3 * t + 1]].pos,
-                            vertices[m->first_vertex + indices[m->first_index + 3 * t + 2]].pos, lit);
-            for (int k = 0; k < 3; ++k) {
-                const orc_vertex *v = &vertices[m->first_vertex + indices[m->first_index + 3 * t + k]];
-                transform_vertex(pvm, v->pos, poly[k].c);
-                poly[k].c[4] = v->uv[0]; poly[k].c[5] = v->uv[1];
-                poly[k].c[6] = v->color[0]; poly[k].c[7] = v->color[1]; poly[k].c[8] = v->color[2];
+                light_terms(cfg, &light, model, corner[0]->pos, corner[1]->pos, corner[2]->pos, lit);
+            for (int c = 0; c < 3; ++c) {
+                const orc_vertex *v = corner[c];
+                transform_vertex(pvm, v->pos, poly[c].c);
+                poly[c].c[4] = v->uv[0]; poly[c].c[5] = v->uv[1];
+                poly[c].c[6] = v->color[0]; poly[c].c[7] = v->color[1]; poly[c].c[8] = v->color[2];
             }
             if (!(cfg->flags & ORC_FLAG_NO_TRIVIAL_REJECT)) {
                 /* all three vertices outside one plane of the true view volume */
@@ -724,11 +771,12 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
             }
             for (int s = 1; s + 1 < n; ++s) { /* fan; sub-triangle index s-1 */
                 cvert tri[3] = { poly[0], poly[s], poly[s + 1] };
-                raster_triangle(&f, tri, prim_id, objects[o].texture, lit);
+                raster_triangle(&f, tri, prim_id, draws[d].texture, lit);
             }
         }
     }
-    free(order);
+    free(draws);
+    free(cat_off);
     if (stats) *stats = f.st;
     return 0;
 }

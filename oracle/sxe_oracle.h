@@ -59,7 +59,10 @@ typedef struct {
  * normal): it restates the flat Blinn-Phong extension that include/sxe.h defines at sxe_set_light,
  * so that the kernels have something to be compared with.  Parity unpinned, like everything here. */
 enum { ORC_SHADE_TEXTURE = 0, ORC_SHADE_VERTEX_COLOR = 1, ORC_SHADE_COLOR_TIMES_TEXTURE = 2, ORC_SHADE_LIT = 3 };
-enum { ORC_FLAG_NO_TRIVIAL_REJECT = 1 };
+/* ORC_FLAG_REFERENCE_INDEXING: the draws as the reference binary records them, indexing flaws
+ * included (src/renderer/drawer.rs:313-347; see draw_list in sxe_oracle.c).  Every object, rendered
+ * or not, then needs a valid texture index. */
+enum { ORC_FLAG_NO_TRIVIAL_REJECT = 1, ORC_FLAG_REFERENCE_INDEXING = 2 };
 
 typedef struct {
     uint32_t width, height;

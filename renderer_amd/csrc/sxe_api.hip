@@ -373,11 +373,14 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     }
 
     // draw order: texture groups ascending, caller order inside a group; unrendered meshes skipped
+    const bool compat = (c->cfg.flags & SXE_FLAG_COMPAT_REFERENCE_INDEXING) != 0;
     std::vector<uint32_t> order;
     order.reserve(ho.size());
     for (uint32_t o = 0; o < ho.size(); ++o) {
         if (ho[o].mesh >= hm.size()) return fail(c, SXE_E_INVALID, "object %u: mesh %u out of range", o, ho[o].mesh);
-        if (!ho[o].rendered) continue;
+        // (the reference files an unrendered mesh under its texture like any other: it takes a
+        // place in its group, src/renderer/drawer.rs:481-487,326-329)
+        if (!ho[o].rendered && !compat) continue;
         if (need_tex && (ho[o].texture < 0 || (uint32_t)ho[o].texture >= c->n_textures))
             return fail(c, SXE_E_INVALID, "object %u: texture %d is not in the texture table (%u entries)", o,
                         ho[o].texture, c->n_textures);
@@ -388,34 +391,132 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     if (need_tex)
         for (uint32_t o : order) max_texture = std::max(max_texture, ho[o].texture);
 
+    // The draw list: which triangles (a mesh of the table), under which object's model matrix, with
+    // which texture.  As the reference means it, every rendered object draws its own mesh under its
+    // own matrix.
+    struct HostDraw {
+        uint32_t mesh, object;
+        int32_t texture;
+    };
+    std::vector<HostDraw> draws;
+    size_t box_meshes_from = SIZE_MAX; // entries of the mesh table from here on are boxes only: no triangles of their own
+    std::vector<uint32_t> object_mesh(ho.size());
+    for (size_t o = 0; o < ho.size(); ++o) object_mesh[o] = ho[o].mesh;
+    if (!compat) {
+        draws.reserve(order.size());
+        for (uint32_t o : order) draws.push_back({ho[o].mesh, o, ho[o].texture});
+    } else {
+        // As the reference's command buffer records it (src/renderer/drawer.rs:313-347), flaws
+        // included.  The vertex and index buffers hold the drawables' meshes one after the other in
+        // caller order, indices rebased (:173-193).  Inside a texture group the i-th mesh, counting
+        // the unrendered ones, is drawn with the uniform at offset i (:326,331): the i-th matrix
+        // of the whole scene, not the mesh's own.  Its index range starts where the ranges of the
+        // draws before it, in group order, end (:313,345-346), whichever drawable's indices lie
+        // there, and an unrendered mesh moves that cursor by nothing (:327-329).
+        std::vector<uint64_t> cat_off(ho.size() + 1, 0); // where each drawable's indices start in that index buffer
+        for (size_t o = 0; o < ho.size(); ++o) cat_off[o + 1] = cat_off[o] + hm[ho[o].mesh].ni;
+        // bounding box, per matrix, of everything drawn under it (what the whole-object visibility test needs)
+        std::vector<MeshDev> boxes(ho.size());
+        for (MeshDev &b : boxes) {
+            b = MeshDev{};
+            for (int k = 0; k < 3; ++k) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+        }
+        uint64_t cursor = 0;
+        uint32_t i = 0;
+        for (size_t d = 0; d < order.size(); ++d, ++i) {
+            const HostObject &o = ho[order[d]];
+            if (d > 0 && ho[order[d - 1]].texture != o.texture) i = 0; // next group
+            if (!o.rendered) continue;
+            const uint32_t n_idx = hm[o.mesh].ni;
+            // the drawable whose indices lie at the cursor (ranges never straddle the end: the
+            // rendered meshes' index counts sum to at most the buffer's length)
+            size_t k = (size_t)(std::upper_bound(cat_off.begin(), cat_off.end(), cursor) - cat_off.begin()) - 1;
+            while (k < ho.size() && cat_off[k + 1] == cat_off[k]) ++k; // (drawables without indices own no position)
+            uint32_t mesh;
+            if (n_idx == 0 || (k < ho.size() && cat_off[k] == cursor && hm[ho[k].mesh].ni == n_idx)) {
+                mesh = n_idx == 0 ? o.mesh : ho[k].mesh; // exactly one drawable's mesh (always, when all meshes are alike)
+            } else {
+                // a range that starts inside a mesh or runs over several: a mesh of its own over
+                // the pooled vertices (index counts are multiples of 3, so triangles stay whole)
+                MeshDev sm{};
+                std::vector<uint32_t> at(n_idx); // pooled position of every index's vertex
+                uint32_t vlo = 0xFFFFFFFFu, vhi = 0;
+                size_t kk = k;
+                for (uint32_t j = 0; j < n_idx; ++j) {
+                    const uint64_t p = cursor + j;
+                    while (p >= cat_off[kk + 1]) ++kk;
+                    const uint32_t src = ho[kk].mesh;
+                    at[j] = meshes[src].vtx_base + hm[src].idx[p - cat_off[kk]];
+                    vlo = std::min(vlo, at[j]);
+                    vhi = std::max(vhi, at[j]);
+                }
+                sm.vtx_base = vlo;
+                sm.n_vtx = vhi - vlo + 1u;
+                sm.idx_base = (uint32_t)idx.size();
+                sm.n_tri = n_idx / 3;
+                if ((uint64_t)idx.size() + n_idx > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "scene pools exceed 2^32 elements");
+                for (int q = 0; q < 3; ++q) { sm.lo[q] = INFINITY; sm.hi[q] = -INFINITY; }
+                for (uint32_t j = 0; j < n_idx; ++j) {
+                    idx.push_back(at[j] - vlo);
+                    for (int q = 0; q < 3; ++q) {
+                        const float p = verts[at[j]].pos[q];
+                        if (p != p) { sm.lo[q] = -INFINITY; sm.hi[q] = INFINITY; }
+                        sm.lo[q] = std::min(sm.lo[q], p);
+                        sm.hi[q] = std::max(sm.hi[q], p);
+                    }
+                }
+                mesh = (uint32_t)meshes.size();
+                meshes.push_back(sm);
+            }
+            draws.push_back({mesh, i, o.texture});
+            MeshDev &b = boxes[i];
+            b.n_tri += meshes[mesh].n_tri;
+            for (int q = 0; q < 3; ++q) {
+                b.lo[q] = std::min(b.lo[q], meshes[mesh].lo[q]);
+                b.hi[q] = std::max(b.hi[q], meshes[mesh].hi[q]);
+            }
+            cursor += n_idx;
+        }
+        // every matrix is tested against the box of what is drawn under it
+        box_meshes_from = meshes.size();
+        for (size_t o = 0; o < ho.size(); ++o) {
+            if (boxes[o].n_tri == 0)
+                for (int q = 0; q < 3; ++q) boxes[o].lo[q] = boxes[o].hi[q] = 0.0f;
+            object_mesh[o] = (uint32_t)meshes.size();
+            meshes.push_back(boxes[o]);
+        }
+    }
+
     // vertex range touched by every run of 256 triangles of every mesh (mesh-local indices)
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ranges(hm.size());
-    for (size_t m = 0; m < hm.size(); ++m) {
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ranges(meshes.size());
+    for (size_t m = 0; m < meshes.size(); ++m) {
+        if (m >= box_meshes_from) break;
         const uint32_t nt = meshes[m].n_tri;
+        const uint32_t *mi = idx.data() + meshes[m].idx_base;
         for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) {
             uint32_t lo = 0xFFFFFFFFu, hi = 0;
             const uint32_t t1 = std::min(nt, t0 + (uint32_t)kSetupThreads);
             for (uint32_t k = 3 * t0; k < 3 * t1; ++k) {
-                lo = std::min(lo, hm[m].idx[k]);
-                hi = std::max(hi, hm[m].idx[k]);
+                lo = std::min(lo, mi[k]);
+                hi = std::max(hi, mi[k]);
             }
             ranges[m].push_back({lo, hi - lo + 1u});
         }
     }
 
-    std::vector<InstDev> insts(order.size());
+    std::vector<InstDev> insts(draws.size());
     std::vector<BlockDesc> blocks;
     uint64_t prims = 0;
-    for (size_t d = 0; d < order.size(); ++d) {
-        const HostObject &o = ho[order[d]];
+    for (size_t d = 0; d < draws.size(); ++d) {
+        const HostDraw &o = draws[d];
         insts[d].mesh = o.mesh;
-        insts[d].object = order[d];
+        insts[d].object = o.object;
         insts[d].texture = o.texture;
         insts[d].prim_base = (uint32_t)prims;
         const uint32_t nt = meshes[o.mesh].n_tri;
         for (uint32_t t0 = 0; t0 < nt; t0 += kSetupThreads) {
             const auto &vr = ranges[o.mesh][t0 / kSetupThreads];
-            blocks.push_back({(uint32_t)d, t0, vr.first, vr.second, order[d], meshes[o.mesh].vtx_base, meshes[o.mesh].idx_base,
+            blocks.push_back({(uint32_t)d, t0, vr.first, vr.second, o.object, meshes[o.mesh].vtx_base, meshes[o.mesh].idx_base,
                               nt, o.texture, (uint32_t)prims, 0u, 0u});
         }
         prims += nt;
@@ -456,8 +557,6 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     SXE_HIP(c, up(c->vblocks, vblocks));
     SXE_HIP(c, up(c->models, models));
     SXE_HIP(c, up(c->transforms, transforms));
-    std::vector<uint32_t> object_mesh(ho.size());
-    for (size_t o = 0; o < ho.size(); ++o) object_mesh[o] = ho[o].mesh;
     SXE_HIP(c, up(c->object_mesh, object_mesh));
     if ((uint64_t)blocks.size() * kSetupThreads * c->view_capacity > 0x7FFFFFFFull) c->view_capacity = 1; // (slots are 32-bit)
     for (FrameSlot &fs : c->slots) {
@@ -972,8 +1071,8 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((k.flags & kDebugMask) && !(getenv("SXE_DEVELOPMENT") && getenv("SXE_DEVELOPMENT")[0] == '1'))
         return fail(nullptr, SXE_E_INVALID, "flags 0x%x: bits 26-31 are development switches (set SXE_DEVELOPMENT=1 to use them)",
                     k.flags & kDebugMask);
-    if (k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask))
-        return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~(SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | kDebugMask));
+    constexpr uint32_t kKnownFlags = SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | SXE_FLAG_COMPAT_REFERENCE_INDEXING | kDebugMask;
+    if (k.flags & ~kKnownFlags) return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~kKnownFlags);
     if (k.n_images == 0) k.n_images = 1;
     if (k.n_images > 65536) return fail(nullptr, SXE_E_CAPACITY, "at most 65536 images");
 

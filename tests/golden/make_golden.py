@@ -74,6 +74,13 @@ def main():
     s = soup_scene(tri, uvs=uv, textures=[scenes.checker_texture(16, 3)], width=43, height=201)
     m = np.tile(IDENT, (1, 1))
     save("sliver_soup_43x201.npz", s, m, IDENT, IDENT, oracle.render(s, m, IDENT, IDENT, 43, 201))
+    # 7. the 64-cube / 3-texture demo world (src/main.rs:201-227) as the reference binary records its
+    # draws (src/renderer/drawer.rs:313-347): the matrix index restarts with every texture group
+    s = scenes.reference_demo_scene(seed=11, width=256, height=192)  # (a seed under which the recorded draws show cubes)
+    m = oracle.to_model(s.transforms)
+    v, p = oracle.camera(s.camera, 256, 192)
+    save("demo_reference_indexing_256x192.npz", s, m, v, p,
+         oracle.render(s, m, v, p, 256, 192, flags=oracle.FLAG_REFERENCE_INDEXING), extra={"reference_indexing": np.array(1)})
 
 
 if __name__ == "__main__":
