@@ -244,11 +244,9 @@ def main():
         step(i)
     fence()
     redraws_before = drawer.stats()["redraws"]
-    drawer.reset_timing_totals()
-    # Events around every kernel cost a few per cent of a frame: every fourth frame of the timed
-    # region is sampled, every frame when that would leave fewer than eight samples.
-    timing_stride = 4 if args.steps >= 32 else 1
-    drawer.set_timing_stride(timing_stride)
+    # The headline: exactly --steps steps between two fences, without any timing event on the
+    # stream (every event costs a few microseconds of stream time, six of them per frame).
+    drawer.set_timing_stride(0)
     t0 = time.perf_counter()
     for i in range(args.steps):
         # frames are enqueued back to back (the library keeps up to three in flight on its
@@ -256,20 +254,43 @@ def main():
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    # per-kernel device times: HIP events the library records on its own stream around every
-    # kernel of the sampled frames of the timed region
-    acc, timed_frames = drawer.timing_totals()
-    stats = drawer.stats()
-    kern = {k: v / max(timed_frames, 1) for k, v in acc.items()}
-    gather_ms = None
-    if pipe:
-        last = args.warmup + args.steps - 1
-        gather_ms = 0.5 * (pipe.last_gather_ms(last) + pipe.last_gather_ms(last - 1)) if args.steps >= 2 else pipe.last_gather_ms(last)
-    per_rank = None
+    redraws_timed = drawer.stats()["redraws"] - redraws_before
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    next_step = args.warmup + args.steps
+    # Per-kernel device times come from a pass of their own after the headline: the same step, every
+    # kernel of every frame bracketed by HIP events the library records on its own stream.
+    sampled_frames = 16
+    drawer.set_timing_stride(1)
+    drawer.reset_timing_totals()
+    for i in range(sampled_frames):
+        step(next_step + i)
+    fence()
+    next_step += sampled_frames
+    acc, timed_frames = drawer.timing_totals()
+    stats = drawer.stats()
+    kern = {k: v / max(timed_frames, 1) for k, v in acc.items()}
+    # Sustained rate: the same step for at least half a second (again without events), so that the
+    # closing fence is spread over thousands of frames and a sampler on the outside sees the GPU busy.
+    drawer.set_timing_stride(0)
+    sustained_steps = int(min(max(0.6 * args.steps / max(elapsed, 1e-6), 32), 20000))
+    t0 = time.perf_counter()
+    for i in range(sustained_steps):
+        step(next_step + i)
+    fence()
+    sustained_elapsed = time.perf_counter() - t0
+    next_step += sustained_steps
+    last_step = next_step - 1
+    gather_ms = None
+    if pipe:
+        gather_ms = 0.5 * (pipe.last_gather_ms(last_step) + pipe.last_gather_ms(last_step - 1))
+    per_rank = None
+    if world > 1:
+        t = torch.tensor([sustained_elapsed], dtype=torch.float64, device=stat_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sustained_elapsed = float(t.item())
         mine = torch.tensor([kern["object_ms"], kern["setup_ms"], kern["finish_ms"], kern["raster_shade_ms"], kern["frame_ms"],
                              gather_ms or 0.0, float(stats["records"]), float(stats["bin_entries"]),
                              float(scissor[1] - scissor[0]) if scissor else float(height)], dtype=torch.float64, device=stat_device)
@@ -286,7 +307,7 @@ def main():
 
     result = None
     if rank == 0:
-        img = (args.warmup + args.steps - 1) & 1
+        img = last_step & 1
         rows = (scissor[1] - scissor[0]) if scissor else height
         depth = drawer.read_depth(img)
         covered_px = int((depth[scissor[0]:scissor[1]] < 1.0).sum()) if scissor else int((depth < 1.0).sum())
@@ -298,10 +319,20 @@ def main():
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic_all = profile_file("pmc_traffic.json") or {}
         valu_all = profile_file("pmc_valu_lds.json") or {}
+        mem_all = profile_file("pmc_mem.json") or {}
+        # the counter summaries are artefacts of tools/profile_round.sh, not of this run: they are stale
+        # when the kernel sources have changed since they were collected
+        from renderer_amd import _build
+        built_from = _build.source_hash()
+        counters_stale = any(f.get("source_hash") != built_from for f in (traffic_all, valu_all, mem_all))
         valu = next((v for k, v in valu_all.items() if isinstance(v, dict) and ("k_" + dom) in k), {})
-        mem = next((v for k, v in (profile_file("pmc_mem.json") or {}).items() if isinstance(v, dict) and ("k_" + dom) in k), {})
+        mem = next((v for k, v in mem_all.items() if isinstance(v, dict) and ("k_" + dom) in k), {})
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_all.get(dom),
+                    "traffic_fetch_factor": traffic_all.get("fetch_factor"),
+                    # (false: profiles/pmc_*.json were collected on exactly these kernel sources)
+                    "counters_stale": counters_stale, "counters_source_hash": traffic_all.get("source_hash"),
+                    "source_hash": built_from,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_ms_per_launch": stage_ms[dom],
                     # what binds the kernel in practice (tools/pmc_valu_lds.sh, profiles/pmc_valu_lds.json):
                     # share of the launch during which the vector ALUs of all SIMDs were issuing
@@ -335,9 +366,14 @@ def main():
             "roofline": roofline,
             "stage_rooflines": stage,
             "kernels_ms": kern,
-            "kernel_timing": {"frames_sampled": int(timed_frames), "stride": timing_stride},
+            "kernel_timing": {"pass": "separate pass of %d frames after the timed region, events around every kernel; the "
+                                      "timed region itself records no events" % sampled_frames,
+                              "frames_sampled": int(timed_frames), "events_in_timed_region": 0},
+            "sustained": {"steps": sustained_steps, "seconds": sustained_elapsed,
+                          "ms_per_step": 1e3 * sustained_elapsed / sustained_steps,
+                          "value": n_prims * frames_per_step * sustained_steps / sustained_elapsed, "unit": "triangles/s"},
             "frame_stats": stats,
-            "redraws_in_timed_region": stats["redraws"] - redraws_before,
+            "redraws_in_timed_region": redraws_timed,
         }
         if gather_ms is not None:
             result["gather_ms"] = gather_ms

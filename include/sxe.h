@@ -243,8 +243,9 @@ int sxe_get_timings(sxe_ctx *ctx, sxe_timings *out);
 int sxe_get_timing_totals(sxe_ctx *ctx, sxe_timings *sums, uint64_t *frames);
 int sxe_reset_timing_totals(sxe_ctx *ctx);
 /* Every event costs a few microseconds of stream time.  With a stride of n only every n-th frame
- * drawn from now on is bracketed by events (default 1: every frame); sxe_get_timings then reports
- * the last such frame and the totals count only those (no counterpart in the reference). */
+ * drawn from now on is bracketed by events (default 1: every frame; 0: no frame, until the stride
+ * is set again); sxe_get_timings then reports the last such frame and the totals count only those
+ * (no counterpart in the reference). */
 int sxe_set_timing_stride(sxe_ctx *ctx, uint32_t every);
 /* Diagnostics: bin occupancy of the last frame, one count per rendered tile in row-major tile
  * order (load-balance analysis; no counterpart in the reference). */

@@ -14,6 +14,17 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-s
                "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """SHA-256 over the kernel and host sources the library is built from: counter summaries under
+    profiles/ carry it, so that a bench line can tell whether they describe the kernels it ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

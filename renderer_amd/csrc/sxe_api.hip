@@ -184,7 +184,7 @@ struct sxe_ctx {
     sxe_timings timings = {};
     sxe_timings timing_totals = {};
     uint64_t timed_frames = 0;
-    uint32_t timing_stride = 1; // events are recorded for every timing_stride-th frame
+    uint32_t timing_stride = 1; // events are recorded for every timing_stride-th frame (0: for none)
     // a rotation-system update that has been asked for but not launched: the next frame's first
     // kernel applies it (anything else that touches transforms or matrices launches it first)
     bool rot_pending = false;
@@ -679,7 +679,7 @@ int flush_rotation(sxe_ctx *c)
 // Per-kernel events cost a few microseconds each; a context may ask for them on a sample of the frames.
 static bool frame_is_timed(const sxe_ctx *c, uint64_t frame)
 {
-    return (c->cfg.flags & SXE_FLAG_TIMING) != 0 && frame % c->timing_stride == 0;
+    return (c->cfg.flags & SXE_FLAG_TIMING) != 0 && c->timing_stride != 0 && frame % c->timing_stride == 0;
 }
 
 // Enqueues the frame of slot `fs` with the work buffers `w`.  A redraw (fresh == false) keeps the
@@ -1504,7 +1504,6 @@ int sxe_get_timing_totals(sxe_ctx *c, sxe_timings *sums, uint64_t *frames)
 int sxe_set_timing_stride(sxe_ctx *c, uint32_t every)
 {
     if (!c) return fail(c, SXE_E_INVALID, "null context");
-    if (every == 0) return fail(c, SXE_E_INVALID, "timing stride must be at least 1");
     c->timing_stride = every;
     return SXE_OK;
 }

@@ -438,8 +438,12 @@ def test_frames_in_flight(orc):
             d.sync()
             sums, frames = d.timing_totals()
             assert frames == 2 and sums["raster_shade_ms"] > 0.0 and sums["object_ms"] > 0.0
-            with pytest.raises(api.SxeError):
-                d.set_timing_stride(0)
+            # a stride of 0 switches the events off: frames are drawn, none is timed
+            d.set_timing_stride(0)
+            d.reset_timing_totals()
+            d.draw(9 % n_images)
+            d.sync()
+            assert d.timing_totals()[1] == 0
             for img in range(n_images):
                 last = max(f for f in range(10) if f % n_images == img)
                 got = {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)}

@@ -10,6 +10,8 @@ counters add up the 256 of them, in shader-clock cycles.
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderer_amd._build import source_hash  # the sources these counters were collected on
 
 CUS = 256
 
@@ -45,6 +47,7 @@ def main():
         out[k] = d
     out["note"] = ("rocprofv3 --pmc, passes of tools/frames.py 3 6 (config 3); every value is the mean over the launches of a "
                    "pass; *_frac = counter / (256 compute units * launch cycles), launch cycles = GRBM_GUI_ACTIVE / 8")
+    out["source_hash"] = source_hash()
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     for k, d in out.items():

@@ -9,6 +9,8 @@ at 64 bytes, so it is doubled before it is added to WRITE_SIZE.
 import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderer_amd._build import source_hash  # the sources these counters were collected on
 
 NAMES = {"k_setup": "setup", "k_raster_shade": "raster_shade", "k_finish": "finish", "k_object": "object",
          "k_clip": "clip", "k_rotation_system": "transform"}
@@ -30,6 +32,7 @@ def main():
     out["note"] = ("bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters, separate --pmc passes, mean over the "
                    "launches of tools/frames.py on config 3); the doubling is calibrated for wide streaming reads and is "
                    "an upper bound for the gathered 16-byte reads of these kernels")
+    out["source_hash"] = source_hash()
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -10,6 +10,8 @@ over all SIMDs (wave-level counters) of the chip; GRBM_GUI_ACTIVE is summed over
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from renderer_amd._build import source_hash  # the sources these counters were collected on
 
 SIMDS = 256 * 4
 
@@ -54,6 +56,7 @@ def main():
     out["note"] = ("rocprofv3 --pmc, three passes of tools/frames.py 3 6 (config 3); every value is the mean over the "
                    "launches of a pass; valu_busy_frac = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * launch cycles), launch "
                    "cycles = GRBM_GUI_ACTIVE / 8")
+    out["source_hash"] = source_hash()
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     for k, d in out.items():
