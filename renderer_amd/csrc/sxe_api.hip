@@ -76,6 +76,8 @@ struct FrameSlot {
     hipEvent_t ev[EV_N] = {};
     hipEvent_t ev_tr[2] = {};
     hipEvent_t done = nullptr;
+    DevBuf<float> models_snap;      // SXE_SHADE_LIT: the model matrices the frame was drawn with
+    LightDev light = {};            // and the light
     bool pending = false, transform_timed = false;
     bool timed = false; // this frame's kernels are bracketed by events
     uint32_t image = 0; // first image of the launch set
@@ -100,6 +102,8 @@ struct WorkBufs {
     FrameCounters *counters = nullptr;
     size_t fan_capacity = 0;
     bool with_clip = true; // k_clip follows k_setup
+    const float *models_lit = nullptr; // the model matrices k_setup lights with (SXE_SHADE_LIT)
+    float *models_snap = nullptr;      // where k_object leaves a copy of them for that, or null
 };
 
 } // namespace
@@ -135,6 +139,7 @@ struct sxe_ctx {
     sxe_config cfg;
     FrameGeom g;
     hipStream_t stream = nullptr;
+    const uint32_t *last_tile_counters = nullptr; // the per-tile counters of the frame enqueued last (diagnostics)
     std::string err;
 
     // scene
@@ -562,6 +567,7 @@ int upload_scene(sxe_ctx *c, const std::vector<HostMesh> &hm, const std::vector<
     for (FrameSlot &fs : c->slots) {
         SXE_HIP(c, fs.visible.reserve(std::max<size_t>(ho.size(), 1) * c->view_capacity));
         SXE_HIP(c, fs.pvm.reserve(std::max<size_t>(models.size(), 16) * c->view_capacity));
+        if (c->cfg.shading == SXE_SHADE_LIT) SXE_HIP(c, fs.models_snap.reserve(std::max<size_t>(models.size(), 16)));
     }
     SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(blocks.size(), 1) * 4 * c->view_capacity)); // (a count per wave)
 
@@ -616,6 +622,11 @@ WorkBufs context_bufs(sxe_ctx *c, FrameSlot &fs)
     w.fan_capacity = c->fan_capacity;
     w.bl = c->bl;
     w.with_clip = c->clip_enabled;
+    // a lit frame keeps the matrices it was lit with: a redraw after an overflow must not see what
+    // the rotation system or update_uniforms have made of them since
+    const bool lit = c->cfg.shading == SXE_SHADE_LIT;
+    w.models_snap = lit ? fs.models_snap.p : nullptr;
+    w.models_lit = lit ? fs.models_snap.p : c->models.p;
     return w;
 }
 
@@ -636,6 +647,7 @@ ObjectArgs object_args(sxe_ctx *c, const WorkBufs &w)
     oa.g = c->g;
     oa.transforms = c->transforms.p;
     oa.models_rw = c->models.p;
+    oa.models_snap = w.models_snap;
     oa.rot_seed = 0;
     oa.rot_first = oa.rot_n = 0;
     oa.rot_delta_ms = 0.0f;
@@ -695,6 +707,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
 
     const size_t ntc = std::max<uint32_t>(nt, 1);
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_BEGIN], s));
+    c->last_tile_counters = w.tile_counters;
+    if (fresh) fs.light = c->light;
     {
         ObjectArgs oa = object_args(c, w);
         oa.g = g;
@@ -719,8 +733,8 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     sa.insts = c->insts.p;
     sa.blocks = c->blocks.p;
     sa.pvm = w.pvm;
-    sa.models = c->models.p;
-    sa.light = c->light;
+    sa.models = w.models_lit;
+    sa.light = fs.light;
     sa.visible = w.visible;
     sa.n_objects = c->n_objects;
     sa.n_blocks = c->n_blocks;
@@ -879,6 +893,8 @@ bool static_bufs(const sxe_ctx *c, unsigned char *base, WorkBufs &w, size_t &fix
     w.bins = reinterpret_cast<uint32_t *>(base + at);
     w.fan_capacity = kNoAllocFan;
     w.with_clip = true; // always: a frame that finds a triangle to clip cannot be drawn again here
+    w.models_lit = c->models.p; // (the call returns when the frame is finished: nothing can change them meanwhile)
+    w.models_snap = nullptr;
     return true;
 }
 
@@ -910,6 +926,7 @@ int ensure_views(sxe_ctx *c, uint32_t views)
         SXE_HIP(c, fs.pv_views.reserve(16 * (size_t)views));
     }
     SXE_HIP(c, c->blk_count.reserve(std::max<size_t>(c->n_blocks, 1) * 4 * views));
+    c->last_tile_counters = nullptr; // (the array may move)
     SXE_HIP(c, c->tile_counters.reserve((kTileCtrWords + 1) * nt));
     SXE_HIP(c, c->tile_launch.reserve(nt));
     SXE_HIP(c, reserve_records(c));
@@ -1171,7 +1188,7 @@ void sxe_destroy(sxe_ctx *c)
         if (st.done) (void)hipEventDestroy(st.done);
     }
     for (FrameSlot &fs : c->slots) {
-        fs.pvm.release(); fs.visible.release(); fs.pv_views.release();
+        fs.pvm.release(); fs.visible.release(); fs.pv_views.release(); fs.models_snap.release();
         if (fs.h_counters) (void)hipHostFree(fs.h_counters);
         for (int i = 0; i < EV_N; ++i) if (fs.ev[i]) (void)hipEventDestroy(fs.ev[i]);
         for (int i = 0; i < 2; ++i) if (fs.ev_tr[i]) (void)hipEventDestroy(fs.ev_tr[i]);
@@ -1419,7 +1436,7 @@ int sxe_draw_views(sxe_ctx *c, const sxe_transform *cameras, uint32_t n, uint32_
         if (rc) return rc;
         fs.image = first_image + v0;
         fs.views = nv;
-        fs.timed = frame_is_timed(c, c->frames_enqueued);
+            fs.timed = frame_is_timed(c, c->frames_enqueued);
         if (nv == 1) c->pv = *reinterpret_cast<const Mat4 *>(&pv[0]); // (a set of one goes the single-view way)
         rc = enqueue_frame(c, fs, true, context_bufs(c, fs));
         if (rc) return rc;
@@ -1622,9 +1639,10 @@ int sxe_read_tile_counts(sxe_ctx *c, uint32_t *counts, size_t size_bytes)
     if (!counts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     rc = sxe_sync(c);
     if (rc) return rc;
+    if (!c->last_tile_counters) return fail(c, SXE_E_STATE, "no frame has been drawn");
     if (need) {
         std::vector<TileCtr> ctr(c->g.n_tiles);
-        SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
+        SXE_HIP(c, hipMemcpy(ctr.data(), c->last_tile_counters, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ctr.size(); ++i) counts[i] = bin_size(ctr[i]);
     }
     return SXE_OK;
@@ -1638,9 +1656,10 @@ int sxe_read_tile_parts(sxe_ctx *c, uint32_t *parts, size_t size_bytes)
     if (!parts || size_bytes < need) return fail(c, SXE_E_INVALID, "destination holds %zu bytes, %zu needed", size_bytes, need);
     rc = sxe_sync(c);
     if (rc) return rc;
+    if (!c->last_tile_counters) return fail(c, SXE_E_STATE, "no frame has been drawn");
     if (need) {
         std::vector<TileCtr> ctr(c->g.n_tiles);
-        SXE_HIP(c, hipMemcpy(ctr.data(), c->tile_counters.p, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
+        SXE_HIP(c, hipMemcpy(ctr.data(), c->last_tile_counters, ctr.size() * sizeof(TileCtr), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ctr.size(); ++i) {
             for (int k = 0; k < kSizeClasses; ++k) parts[5 * i + k] = ctr[i].cnt[k];
             parts[5 * i + 4] = ctr[i].multi;

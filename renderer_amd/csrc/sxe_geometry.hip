@@ -88,6 +88,7 @@ __global__ void k_object(ObjectArgs a)
             M.m[4 * c] = v.x; M.m[4 * c + 1] = v.y; M.m[4 * c + 2] = v.z; M.m[4 * c + 3] = v.w;
         }
     }
+    if (a.models_snap && view == 0) store_model(a.models_snap, i, M);
     const Mat4 R = mul(PV, M);
     const size_t vi = (size_t)view * a.n + i;
     float4 *dst = reinterpret_cast<float4 *>(a.pvm + 16 * vi);

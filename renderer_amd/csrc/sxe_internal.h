@@ -182,6 +182,7 @@ struct ObjectArgs {
     // transforms before the matrices are derived (rot_n == 0: the model matrices are read as they are)
     sxe_transform *transforms;
     float *models_rw;
+    float *models_snap;          // a copy of the frame's model matrices kept with the frame (SXE_SHADE_LIT), or null
     uint64_t rot_seed;
     uint32_t rot_first, rot_n;
     float rot_delta_ms;

@@ -478,6 +478,35 @@ def test_frames_in_flight_with_late_overflow(orc):
             assert_frames_equal(got, refs[img], what="late overflow, image %d" % img)
 
 
+def test_lit_frames_in_flight_with_late_overflow_keep_their_own_light_and_matrices(orc):
+    """A lit frame that overflows is drawn again when it is retired, after younger frames have
+    rotated the models and the light has changed: it must be lit as it was when it was drawn
+    (matrices and light are kept with the frame, like its projection matrices)."""
+    rng = np.random.default_rng(10)
+    s = scenes.sphere_field_scene(40, 31, 2.5, (-9.0, -4.0), 512, 384, n_textures=2, tex_size=64)
+    w, h = s.size
+    view, proj = orc.camera(s.camera, w, h)
+    lights = [dict(to_light=(0.3, 0.8, 0.5), ambient=0.2), dict(to_light=(-0.7, 0.1, 0.6), ambient=0.35, specular=0.6)]
+    t = s.transforms.copy()
+    refs = []
+    with api.HipDrawer(w, h, n_images=2, coverage=True, shading=api.SHADE_LIT) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        for f in range(2):  # both in flight before the first one is looked at
+            d.set_light(**lights[f])
+            d.rotation_system(5, f, 900.0)
+            orc.rotation_system(t, 5, f, 900.0)
+            d.draw(f)
+            refs.append(orc.render(s, orc.to_model(t), view, proj, w, h, shading=orc.SHADE_LIT, light=lights[f]))
+        d.sync()
+        assert d.stats()["redraws"] >= 2  # (40 spheres of 1024 triangles close to the camera outgrow the first bins)
+        for img in (0, 1):
+            got = {"color": d.read_color(img), "depth": d.read_depth(img), "prim": d.read_coverage(img)}
+            assert_frames_equal(got, refs[img], what="lit, late overflow, image %d" % img)
+    assert not np.array_equal(refs[0]["color"], refs[1]["color"])
+    del rng
+
+
 def test_clipping_that_appears_after_quiet_frames(orc):
     """The clip kernel is left out after some frames without a triangle to clip; the first frame
     that needs it again must still come out right (it is drawn again), also with frames in flight."""
