@@ -18,6 +18,8 @@ pub const SXE_FLAG_WRITE_COVERAGE: u32 = 1;
 pub const SXE_FLAG_TIMING: u32 = 2;
 /// The draw list as the reference binary records it, indexing flaws included (src/renderer/drawer.rs:313-347).
 pub const SXE_FLAG_COMPAT_REFERENCE_INDEXING: u32 = 4;
+/// Colour images in B, G, R, A byte order (the Bgra8Srgb surface format of src/renderer/presenter.rs:472-478).
+pub const SXE_FLAG_BGRA: u32 = 8;
 
 #[repr(C)]
 pub struct sxe_ctx {

@@ -55,6 +55,10 @@ extern "C" {
  * Every object then needs a valid texture index, rendered or not (it takes a place in its group).
  * sxe_read_clip_positions is not affected: it reports every drawable's vertices under its own matrix. */
 #define SXE_FLAG_COMPAT_REFERENCE_INDEXING 4u
+/* Store the colour images in B, G, R, A byte order.  The reference renders into the first sRGB
+ * format its surface offers (src/renderer/presenter.rs:472-478), which on X11 is Bgra8Srgb; the
+ * default here is R, G, B, A (its fallback, Rgba8Srgb).  Same values, other byte order. */
+#define SXE_FLAG_BGRA 8u
 
 #define SXE_MAX_DIM 8192u          /* width and height limit (8K frames fit) */
 #define SXE_MAX_PRIMS (1u << 29)   /* triangles per frame */
@@ -201,19 +205,25 @@ int sxe_draw(sxe_ctx *ctx, uint32_t image_index);
 int sxe_draw_views(sxe_ctx *ctx, const sxe_transform *cameras, uint32_t n, uint32_t first_image);
 /* The fence wait of src/renderer/drawer.rs:416-424.  Reports deferred device-side failures. */
 int sxe_sync(sxe_ctx *ctx);
-/* sxe_draw + sxe_sync for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs (the
- * context's scene, uniforms and camera) and same output (image `image_index`) as sxe_draw, but every
- * work buffer of the frame (per-object matrices, triangle records, bin tables, bins) lives in a
- * static device array of SXE_NOALLOC_SCRATCH_BYTES that is part of the library's code object; the
- * call makes no hipMalloc/hipFree and returns when the frame is finished.  Scenes whose work buffers
- * do not fit fail with SXE_E_CAPACITY instead of growing anything: the array must hold about 100 bytes
- * per submitted triangle (148 with a vertex-colour shading mode; objects count in steps of 256
- * triangles) and 72 bytes per screen tile; what is left is divided evenly among the tiles for their
- * bins (4 bytes per entry), and a frame whose fullest tile needs more than its share fails as well.
- * Room for roughly 200,000 triangles at 1080p.  No frame of sxe_draw may
- * be in flight on the context (SXE_E_STATE; call sxe_sync first).  Every call on one GPU uses that
- * GPU's one array, from whatever context or thread: calls that overlap on a GPU race. */
+/* sxe_draw + sxe_sync for callers that cannot allocate (tight serving loops with a fixed memory
+ * budget, harnesses that forbid hipMalloc between frames).  No counterpart in the reference.  Same
+ * inputs (the context's scene, uniforms and camera) and same output (image `image_index`) as
+ * sxe_draw, but every work buffer of the frame (per-object matrices, triangle records, bin tables,
+ * bins) lives in a static device array of SXE_NOALLOC_SCRATCH_BYTES that is part of the library's
+ * code object; the call makes no hipMalloc/hipFree and returns when the frame is finished (it waits
+ * on the host for the frame's event, so it cannot itself be recorded into a HIP graph).
+ * Limits (SXE_E_CAPACITY instead of growing anything):
+ *   - the array must hold about 100 bytes per submitted triangle (148 with a vertex-colour shading
+ *     mode; objects count in steps of 256 triangles) and 72 bytes per screen tile;
+ *   - what is left is divided evenly among the tiles for their bins (4 bytes per entry), at least 768
+ *     entries each: frames of more than about 10,000 tiles (any 8K frame) do not fit whatever the
+ *     scene, and a frame whose fullest tile needs more than its share fails as well;
+ *   - at most 4096 triangles of a frame may cross the near, far or a guard-band plane, and their
+ *     clipped pieces may number at most 4096.
+ * Room for roughly 200,000 triangles at 1080p.  No frame of sxe_draw may be in flight on the
+ * context (SXE_E_STATE; call sxe_sync first).  Every call on one GPU uses that GPU's one array, from
+ * whatever context or thread: a call that finds another one in progress on its GPU returns
+ * SXE_E_STATE at once and draws nothing. */
 int sxe_draw_noalloc(sxe_ctx *ctx, uint32_t image_index);
 
 /* ---- readback: stands in for Presenter::present (src/renderer/presenter.rs:415-430) ---- */

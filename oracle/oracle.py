@@ -22,6 +22,7 @@ SHADE_TEXTURE, SHADE_VERTEX_COLOR, SHADE_COLOR_TIMES_TEXTURE, SHADE_LIT = 0, 1, 
 # the light of SHADE_LIT (an extension without a reference counterpart): the defaults of sxe_default_light
 DEFAULT_LIGHT = dict(to_light=(0.3, 0.8, 0.5), to_viewer=(0.0, 0.0, 1.0), ambient=0.2, diffuse=0.7, specular=0.3, shininess_log2=5)
 FLAG_NO_TRIVIAL_REJECT = 1
+FLAG_BGRA = 4  # colour target in B, G, R, A byte order
 FLAG_REFERENCE_INDEXING = 2  # the draws as the reference binary records them (src/renderer/drawer.rs:313-347)
 
 

@@ -777,6 +777,15 @@ static int render_band(const orc_config *cfg, const orc_vertex *vertices, const 
     }
     free(draws);
     free(cat_off);
+    /* the target's byte order: blending worked on the channels by name; a Bgra8 target holds them
+     * with red and blue exchanged (src/renderer/presenter.rs:472-478) */
+    if (cfg->flags & ORC_FLAG_BGRA)
+        for (int j = y0; j < y1; ++j)
+            for (uint32_t i = 0; i < cfg->width; ++i) {
+                uint8_t *px = out_rgba + 4 * ((size_t)j * cfg->width + i), t = px[0];
+                px[0] = px[2];
+                px[2] = t;
+            }
     if (stats) *stats = f.st;
     return 0;
 }

@@ -62,7 +62,9 @@ enum { ORC_SHADE_TEXTURE = 0, ORC_SHADE_VERTEX_COLOR = 1, ORC_SHADE_COLOR_TIMES_
 /* ORC_FLAG_REFERENCE_INDEXING: the draws as the reference binary records them, indexing flaws
  * included (src/renderer/drawer.rs:313-347; see draw_list in sxe_oracle.c).  Every object, rendered
  * or not, then needs a valid texture index. */
-enum { ORC_FLAG_NO_TRIVIAL_REJECT = 1, ORC_FLAG_REFERENCE_INDEXING = 2 };
+/* ORC_FLAG_BGRA: the colour target in B, G, R, A byte order (Bgra8Srgb, the first sRGB surface
+ * format on X11, src/renderer/presenter.rs:472-478); the default is R, G, B, A (Rgba8Srgb). */
+enum { ORC_FLAG_NO_TRIVIAL_REJECT = 1, ORC_FLAG_REFERENCE_INDEXING = 2, ORC_FLAG_BGRA = 4 };
 
 typedef struct {
     uint32_t width, height;

@@ -9,6 +9,7 @@
 #include "sxe_srgb_tables.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -118,6 +119,17 @@ namespace {
 
 std::mutex g_scratch_lock;
 unsigned char *g_scratch_ptr[kMaxDevices] = {}; // device address of `scratch` on each device, set by sxe_create
+std::atomic<bool> g_scratch_busy[kMaxDevices];  // a call of sxe_draw_noalloc is using the device's array
+
+// Holds a device's static array for the duration of one sxe_draw_noalloc call.
+struct ScratchHold {
+    std::atomic<bool> *flag = nullptr;
+    bool mine = false;
+    explicit ScratchHold(int device) : flag(&g_scratch_busy[device]) { mine = !flag->exchange(true, std::memory_order_acquire); }
+    ~ScratchHold() { if (mine) flag->store(false, std::memory_order_release); }
+    ScratchHold(const ScratchHold &) = delete;
+    ScratchHold &operator=(const ScratchHold &) = delete;
+};
 
 // With `device` current: looks up where this device holds its copy of `scratch`.
 hipError_t init_scratch(int device)
@@ -808,6 +820,7 @@ int enqueue_frame(sxe_ctx *c, FrameSlot &fs, bool fresh, const WorkBufs &w)
     const bool direct = nt > 0 && fs.d_counters && !(c->cfg.flags & kDebugSkipAtomic);
     ra.host_counters = direct ? fs.d_counters : nullptr;
     ra.blend_scene = c->blend_scene ? 1u : 0u;
+    ra.bgra = (c->cfg.flags & SXE_FLAG_BGRA) ? 1u : 0u;
     SXE_HIP(c, launch_raster_shade(ra, s));
     SXE_HIP(c, launch_raster_blend(ra, s)); // (only when a texture is translucent: the tiles the kernel above left out)
     if (timing) SXE_HIP(c, hipEventRecord(fs.ev[EV_RASTER], s));
@@ -1088,7 +1101,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((k.flags & kDebugMask) && !(getenv("SXE_DEVELOPMENT") && getenv("SXE_DEVELOPMENT")[0] == '1'))
         return fail(nullptr, SXE_E_INVALID, "flags 0x%x: bits 26-31 are development switches (set SXE_DEVELOPMENT=1 to use them)",
                     k.flags & kDebugMask);
-    constexpr uint32_t kKnownFlags = SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | SXE_FLAG_COMPAT_REFERENCE_INDEXING | kDebugMask;
+    constexpr uint32_t kKnownFlags = SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | SXE_FLAG_COMPAT_REFERENCE_INDEXING | SXE_FLAG_BGRA | kDebugMask;
     if (k.flags & ~kKnownFlags) return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~kKnownFlags);
     if (k.n_images == 0) k.n_images = 1;
     if (k.n_images > 65536) return fail(nullptr, SXE_E_CAPACITY, "at most 65536 images");
@@ -1473,13 +1486,23 @@ int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
         base = g_scratch_ptr[c->cfg.device];
     }
     if (!base) return fail(c, SXE_E_DEVICE, "the static work array was not located on device %d", c->cfg.device);
+    // one call at a time per GPU: two frames in the one array would overwrite each other's records
+    const ScratchHold hold(c->cfg.device);
+    if (!hold.mine)
+        return fail(c, SXE_E_STATE, "another sxe_draw_noalloc call is using the static work array of device %d", c->cfg.device);
     WorkBufs w;
     size_t fixed = 0;
-    if (!static_bufs(c, base, w, fixed))
+    if (!static_bufs(c, base, w, fixed)) {
+        if (fixed < kScratchBytes)
+            return fail(c, SXE_E_CAPACITY,
+                        "the frame has %u screen tiles: after %zu bytes of records and tables the static work array of %zu "
+                        "bytes leaves fewer than 768 bin entries for each of them (frames above about 10,000 tiles never fit)",
+                        c->g.n_tiles, fixed, kScratchBytes);
         return fail(c, SXE_E_CAPACITY,
                     "scene needs %zu bytes of record and table space, the static work array holds %zu "
                     "(%u setup work items of 256 triangles, %u tiles, %u objects)",
                     fixed, kScratchBytes, c->n_blocks, c->g.n_tiles, c->n_objects);
+    }
     // Nothing of an earlier call's contents is relied upon: the frame's first kernel clears the
     // counters and per-tile tables, and every other table entry is written before it is read.
     FrameSlot &fs = c->slots[c->frames_enqueued % kFrameSlots];

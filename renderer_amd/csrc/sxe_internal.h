@@ -308,6 +308,7 @@ struct RasterArgs {
     uint32_t shading;
     uint32_t debug;
     uint32_t blend_scene; // tiles flagged kTileBlend are left to k_raster_blend
+    uint32_t bgra;        // the colour image is stored in B, G, R, A byte order
 };
 
 constexpr int kMaxDevices = 64; // device ordinals the library keeps per-device state for

@@ -165,8 +165,10 @@ __device__ inline TexelQuad texel_quad(const TexDev &t, float u, float v)
     return q;
 }
 
-// sRGB decode of every texel before filtering.  Only the colour channels: every texel's alpha is
-// 255 (the texture upload rejects anything else), and filtering four ones gives exactly one.
+// sRGB decode of every texel before filtering.  Only the colour channels: the tiles this kernel
+// renders hold only triangles whose texture is opaque (TexDev::flags == 0: k_setup flags every tile
+// that a triangle with a translucent texture touches with kTileBlend, and those tiles are left to
+// k_raster_blend), so every texel's alpha is 255, and filtering four ones gives exactly one.
 __device__ inline void filter_quad(const float *dec, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, float ax,
                                    float ay, float out[4])
 {
@@ -179,6 +181,13 @@ __device__ inline void filter_quad(const float *dec, uint32_t t00, uint32_t t10,
         out[k] = top + ay * (bot - top);
     }
     out[3] = 1.0f;
+}
+
+// The stored colour in the byte order of the target: R, G, B, A as shaded, or B, G, R, A
+// (src/renderer/presenter.rs:472-478 takes whichever sRGB format the surface lists first).
+__device__ inline uint32_t target_order(uint32_t rgba, uint32_t bgra)
+{
+    return bgra ? __builtin_amdgcn_perm(rgba, rgba, 0x03000102u) : rgba;
 }
 
 __device__ inline float clamp_depth(float z)
@@ -379,6 +388,11 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
         // covering triangle whose depth plane gives exactly the winning depth is taken.
         const long long sx = 256 * px + 128, sy = 256 * py + 128;
         const uint32_t fan_base = h.fan_or_ra, n_fan = h.tex_fan >> 24;
+        // (should no fan triangle reproduce the winning depth bit for bit, the first one that covers
+        // the sample is taken, rather than the primitive's own slot, which holds no planes; the
+        // match relies on raster_lane, raster_wide and this loop evaluating the depth with one and
+        // the same expression)
+        bool found = false;
         for (uint32_t f = 0; f < n_fan; ++f) {
             // (the record's halves one after the other, the depth plane only for a triangle that
             // covers: the whole record held through the loop costs the shading of every pixel registers)
@@ -399,11 +413,13 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
             const uint4 fp = reinterpret_cast<const uint4 *>(a.rast)[2 * (size_t)(fan_base + f) + 1]; // z0, dz1, dz2, rA
             const float fl1 = (float)R1 * __uint_as_float(fp.w), fl2 = (float)R2 * __uint_as_float(fp.w);
             const float fz = clamp_depth((__uint_as_float(fp.x) + fl1 * __uint_as_float(fp.y)) + fl2 * __uint_as_float(fp.z));
-            if (__float_as_uint(fz) == __float_as_uint(w.depth)) {
+            const bool exact = __float_as_uint(fz) == __float_as_uint(w.depth);
+            if (exact || !found) {
                 slot = fan_base + f;
                 r = fr;
-                break;
+                found = true;
             }
+            if (exact) break;
         }
         h = a.shade[slot];
     }
@@ -471,9 +487,10 @@ __device__ inline void shade_end(const RasterArgs &a, const PixelMid &m, const f
         }
     }
     // BlendState::ALPHA (src/renderer/drawer.rs:660-663) over the cleared sRGB8 target:
-    // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 in every shading mode
-    // (textures must be opaque, vertex colours have no alpha), and then the blend returns Cs and 1
-    // bit for bit, so it is not evaluated.
+    // C = Cs * As + Cd * (1 - As), A = As + Ad * (1 - As).  As is exactly 1 for every fragment this
+    // kernel shades (the textures of a tile that reaches it are opaque, see filter_quad; vertex
+    // colours have no alpha), and then the blend returns Cs and 1 bit for bit, so it is not
+    // evaluated and only the depth winner is shaded.
     const uint32_t cr = srgb_encode_lds(s_enc, src[0]);
     const uint32_t cg = srgb_encode_lds(s_enc, src[1]);
     const uint32_t cb = srgb_encode_lds(s_enc, src[2]);
@@ -562,7 +579,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const int32_t i = tpx + (tid & (kTile - 1)), j = tpy + (tid / kTile) + k * (kRasterThreads / kTile);
             if (i > cx1 || j < cy0 || j > cy1) continue;
             const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
-            reinterpret_cast<uint32_t *>(a.out_color)[p] = a.clear_code;
+            reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(a.clear_code, a.bgra);
             a.out_depth[p] = 1.0f;
             if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
         }
@@ -777,7 +794,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
         const unsigned long long v = vis[tid + k * kRasterThreads];
         const bool covered = (uint32_t)(v >> 32) != 0x3F800000u; // (a fragment's depth is below 1)
         const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = covered ? (uint32_t)v : a.clear_code;
+        reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(covered ? (uint32_t)v : a.clear_code, a.bgra);
         a.out_depth[p] = __uint_as_float((uint32_t)(v >> 32));
         if (COVERAGE && !covered) a.out_prim[p] = 0xFFFFFFFFu;
     }
@@ -1115,7 +1132,7 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
     const int32_t ox = tpx + (tid & 31), oy = tpy + (tid >> 5);
     if (ox <= cx1 && oy >= cy0 && oy <= cy1) {
         const size_t p = (size_t)(__umul24((uint32_t)oy, a.g.width) + (uint32_t)ox);
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = s_out[tid];
+        reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(s_out[tid], a.bgra);
         a.out_depth[p] = __uint_as_float(s_out[kTile * kTile + tid]);
         if (COVERAGE) a.out_prim[p] = s_out[2 * kTile * kTile + tid];
     }

@@ -86,3 +86,76 @@ def test_noalloc_rejects_what_does_not_fit_and_frames_in_flight():
         d.sync()
         d.draw_noalloc(1)
         assert np.array_equal(d.read_color(0), d.read_color(1))
+
+
+def test_noalloc_calls_that_overlap_on_one_gpu_are_refused_not_raced():
+    """Two threads, two contexts, one GPU, one static array: a call that finds the other one in
+    progress returns SXE_E_STATE and draws nothing; every call that went through gives the frame
+    sxe_draw gives."""
+    import threading
+    scenes_ = [scenes.config_scene(2, scale=0.5), scenes.config_scene(2, scale=0.3)]
+    ctxs = []
+    try:
+        for s in scenes_:
+            d = api.HipDrawer(s.size[0], s.size[1], n_images=2, coverage=True)
+            d.update_scene(s)
+            d.update_camera(s.camera)
+            d.draw(0)
+            d.sync()
+            ctxs.append((d, _images(d, 0)))
+        outcome = [{"ok": 0, "busy": 0, "bad": []} for _ in ctxs]
+        start = threading.Barrier(len(ctxs))
+
+        def worker(k):
+            d, ref = ctxs[k]
+            start.wait()
+            for _ in range(40):
+                try:
+                    d.draw_noalloc(1)  # (ctypes releases the interpreter lock for the duration of the call)
+                except api.SxeError as e:
+                    if e.code == api.E_STATE and "another sxe_draw_noalloc" in str(e):
+                        outcome[k]["busy"] += 1
+                    else:
+                        outcome[k]["bad"].append(str(e))
+                    continue
+                outcome[k]["ok"] += 1
+                got = _images(d, 1)
+                if not (np.array_equal(got["color"], ref["color"]) and np.array_equal(got["depth"], ref["depth"])):
+                    outcome[k]["bad"].append("frame differs")
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(ctxs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for o in outcome:
+            assert not o["bad"], o["bad"][:3]
+            assert o["ok"] >= 1 and o["ok"] + o["busy"] == 40
+    finally:
+        for d, _ in ctxs:
+            d.close()
+
+
+def test_noalloc_says_when_the_tile_count_is_the_limit_and_tile_diagnostics_follow_the_frame():
+    c = scenes.cube_scene(7680, 4320)  # 32,400 tiles: no room for bins, however small the scene
+    with api.HipDrawer(7680, 4320, n_images=1) as d:
+        d.update_scene(c)
+        d.update_camera(c.camera)
+        with pytest.raises(api.SxeError) as e:
+            d.draw_noalloc(0)
+        assert e.value.code == api.E_CAPACITY and "screen tiles" in str(e.value)
+    s = scenes.config_scene(2, scale=0.3)
+    with api.HipDrawer(s.size[0], s.size[1]) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        want = d.tile_counts().copy()
+        small = scenes.cube_scene(s.size[0], s.size[1])
+        d.update_scene(small)
+        d.update_camera(small.camera)
+        d.draw_noalloc(0)
+        got = d.tile_counts()  # of the frame just drawn, which worked in the static array
+        assert got.sum() > 0 and got.sum() < want.sum()
+        d.draw(0)
+        d.sync()
+        assert np.array_equal(d.tile_counts(), got)
