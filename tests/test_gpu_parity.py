@@ -723,6 +723,70 @@ def test_full_size_config5_views(orc):
     assert seen > 10000
 
 
+def test_full_size_config5_one_ranks_share_through_view_sets(orc):
+    """Config 5 the way a rank runs it: its 512 of the 4096 views (views_for_rank of eight) at
+    512x512 through sxe_draw_views, which cuts them into launch sets of 64.  Sixteen of them against
+    the oracle, all 512 against update_camera + draw of the same view, bit for bit; the rate of the
+    set path is printed (config 5's figure)."""
+    import hashlib
+    import time
+    from renderer_amd import shard
+    s = scenes.config_scene(5)
+    w, h = s.size
+    assert (w, h) == (512, 512) and len(s.objects) == 100
+    cams = scenes.orbit_cameras(4096, 5, radius=60.0, target=(0.0, 0.0, -22.5))
+    first, end = shard.views_for_rank(4096, 8, 3)
+    assert end - first == 512
+    cams = np.ascontiguousarray(cams[first:end])
+    models = orc.to_model(s.transforms)
+
+    def digest(d, k):
+        return hashlib.sha1(d.read_color(k).tobytes() + d.read_depth(k).tobytes()).digest()
+
+    with api.HipDrawer(w, h, n_images=512) as d:
+        d.update_scene(s)
+        d.draw_views(cams)  # (the first pass sizes the work buffers for sets of 64 views)
+        d.sync()
+        t0 = time.perf_counter()
+        d.draw_views(cams)
+        d.sync()
+        dt = time.perf_counter() - t0
+        print("config 5: 512 views of 512x512 in %.2f ms through sxe_draw_views: %.0f views/s" % (1e3 * dt, 512 / dt))
+        by_set = [digest(d, k) for k in range(512)]
+        sampled = list(range(0, 512, 37)) + [63, 64, 511]
+        for k in sampled[:16]:
+            view, proj = orc.camera(cams[k:k + 1], w, h)
+            ref = orc.render(s, models, view, proj, w, h)
+            assert np.array_equal(d.read_color(k), ref["color"]), "view %d colour" % k
+            assert np.array_equal(d.read_depth(k).view(np.uint32), ref["depth"].view(np.uint32)), "view %d depth" % k
+        assert d.stats()["redraws"] <= 4
+    with api.HipDrawer(w, h, n_images=3) as d:
+        d.update_scene(s)
+        one_by_one = []
+        for k in range(512):
+            d.update_camera(cams[k:k + 1])
+            d.draw(k % 3)
+            d.sync()
+            one_by_one.append(digest(d, k % 3))
+    differing = [k for k in range(512) if by_set[k] != one_by_one[k]]
+    assert not differing, "views %s differ between the set and the single draw" % differing[:8]
+    assert len(set(by_set)) > 500  # (they are different views)
+
+
+def test_config1_lit_cube_at_800x600(orc):
+    """Config 1 as BASELINE.json words it ("lit textured cube, 800x600"): the reference's cube, posed
+    as the benchmark poses it, textured and lit (the lit mode is this build's extension: parity is
+    with the oracle's restatement of the definition in include/sxe.h)."""
+    s = scenes.config_scene(1)
+    assert s.size == (800, 600) and len(s.objects) == 1
+    for shading in (api.SHADE_TEXTURE, api.SHADE_LIT):
+        ref = render_oracle(orc, s, shading=shading)
+        got = render_hip(s, shading=shading)
+        assert_frames_equal(got, ref, what="config 1 at 800x600, shading %d" % shading)
+        assert (ref["prim"] != 0xFFFFFFFF).sum() > 50000
+    assert tuple(ref["color"][0, 0]) == (218, 124, 0, 255)
+
+
 def test_views_drawn_as_one_set_equal_views_drawn_one_by_one(orc):
     """sxe_draw_views: the view is a grid dimension of every kernel.  A set of views (more than one
     launch set: 70 views of the small scene) against the oracle and against update_camera + draw,
