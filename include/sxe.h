@@ -160,8 +160,8 @@ const char *sxe_version(void);
  * textures (alpha 255 everywhere, as every JPEG-derived reference texture is) are shaded once per
  * pixel.  A texture with any other alpha makes the screen tiles its triangles touch take an ordered
  * path that depth-tests and blends every fragment in submission order (BlendState::ALPHA,
- * src/renderer/drawer.rs:660-663): exact, much slower, and limited to 4096 bin entries per such
- * 32x32 tile (SXE_E_CAPACITY from sxe_sync beyond).
+ * src/renderer/drawer.rs:660-663): exact and much slower (a 32x32 tile that holds more than 4096
+ * such triangles is sorted and blended in consecutive stretches of the submission order).
  * On the device a texture is kept as a table of its (width + 1) x (height + 1) bilinear footprints
  * (the four texels of every possible sample, clamp to edge applied; 16 bytes each) next to the
  * texels as given: about 20 bytes of device memory per texel; all tables together hold fewer than

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsxe_hip.so")
+# (SXE_LIB: a development build of the library to load instead, e.g. one of exp/libsxe_*.so of tools/exp.sh)
+LIB_PATH = os.environ.get("SXE_LIB") or os.path.join(HERE, "libsxe_hip.so")
 
 VERTEX = np.dtype([("pos", "<f4", 3), ("color", "<f4", 3), ("uv", "<f4", 2)])
 TRANSFORM = np.dtype([("position", "<f4", 3), ("scale", "<f4", 3), ("rotation", "<f4", 4)])

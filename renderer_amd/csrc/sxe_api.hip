@@ -955,20 +955,13 @@ int retire_oldest(sxe_ctx *c)
     SXE_HIP(c, hipEventSynchronize(fs.done));
     if (fs.h_counters->overflow) {
         SXE_HIP(c, hipStreamSynchronize(c->stream));
-        uint32_t hopeless = 0, blend_max = 0; // a frame in flight that no regrowth can hold
-        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
-            const FrameCounters &k = *c->slots[f % kFrameSlots].h_counters;
-            hopeless |= k.overflow & kOverflowBlend;
-            if (k.total_pairs > 0xFFFFFFFFull) hopeless |= kOverflowPairs; // (then a region has overflowed as well)
-            blend_max = std::max(blend_max, k.blend_max);
-        }
+        bool hopeless = false; // a frame in flight that no regrowth can hold
+        for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f)
+            hopeless = hopeless || c->slots[f % kFrameSlots].h_counters->total_pairs > 0xFFFFFFFFull; // (then a region has overflowed as well)
         if (hopeless) {
             for (FrameSlot &x : c->slots) x.pending = false;
             c->frames_retired = c->frames_enqueued;
-            if (hopeless & kOverflowPairs) return fail(c, SXE_E_CAPACITY, "frame has more than 2^32 - 1 (triangle, tile) bin entries");
-            return fail(c, SXE_E_CAPACITY,
-                        "a screen tile with translucent triangles holds %u bin entries: blending in submission order takes at "
-                        "most %u per tile", blend_max, kBlendMaxEntries);
+            return fail(c, SXE_E_CAPACITY, "frame has more than 2^32 - 1 (triangle, tile) bin entries");
         }
         for (uint64_t f = c->frames_retired; f < c->frames_enqueued; ++f) {
             FrameSlot &r = c->slots[f % kFrameSlots];
@@ -1516,9 +1509,6 @@ int sxe_draw_noalloc(sxe_ctx *c, uint32_t image_index)
     const FrameCounters &k = *fs.h_counters;
     if (k.overflow) {
         c->images[image_index].drawn = false;
-        if (k.overflow & kOverflowBlend)
-            return fail(c, SXE_E_CAPACITY, "a screen tile with translucent triangles holds %u bin entries: blending in submission "
-                                           "order takes at most %u per tile", k.blend_max, kBlendMaxEntries);
         if (k.overflow & kOverflowBins)
             return fail(c, SXE_E_CAPACITY,
                         "frame needs bins of %u/%u/%u/%u/%u entries per tile (size classes 0-3, late entries), the static work "

@@ -1041,8 +1041,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(FinishArgs a)
                 if ((uint32_t)mine_v > pick_region(a.bl.cap, (uint32_t)(lane - 1))) flags = kOverflowBins;
             }
             if (lane == 6) {
-                atomicMax(&a.counters->blend_max, (uint32_t)mine_v);
-                if ((uint32_t)mine_v > kBlendMaxEntries) flags = kOverflowBlend;
+                atomicMax(&a.counters->blend_max, (uint32_t)mine_v); // (statistics: k_raster_blend takes such a tile in pieces)
             }
             for (int d = 32; d; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d);
             if (lane == 0 && flags) atomicOr(&a.counters->overflow, flags);

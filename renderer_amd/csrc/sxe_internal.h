@@ -33,10 +33,9 @@ constexpr uint32_t kDebugMask = 63u << 26;
 constexpr uint32_t kOverflowBins = 1u, kOverflowClip = 2u;
 constexpr uint32_t kOverflowNoClip = 4u; // a triangle needs clipping in a frame enqueued without the clip kernel
 constexpr uint32_t kOverflowPairs = 8u;  // more than 2^32 - 1 (triangle, tile) pairs: beyond any bin array (found by the host)
-constexpr uint32_t kOverflowBlend = 16u; // a tile with translucent triangles holds more entries than the ordered path sorts
 // Tiles that hold a triangle with a translucent texture are rendered by k_raster_blend: every
 // fragment is depth-tested and blended in submission order (BlendState::ALPHA,
-// src/renderer/drawer.rs:660-663), which takes the tile's entries sorted; at most this many.
+// src/renderer/drawer.rs:660-663), which takes the tile's entries sorted, this many at a time.
 constexpr uint32_t kBlendMaxEntries = 4096;
 constexpr uint32_t kTileBlend = 1u;      // TileCtr::flags
 

@@ -862,7 +862,8 @@ __device__ inline void filter_quad_rgba(const float *dec, const float *un, uint3
 }
 
 // One workgroup of sixteen waves per flagged tile; a wave owns a block of 8x8 pixels, a thread one
-// pixel.  The tile's entries are sorted by submission order (a record's rank, then its record
+// pixel.  The tile's entries (kBlendMaxEntries at a time: a fuller tile is taken in consecutive
+// stretches of the submission order) are sorted by submission order (a record's rank, then its record
 // number: the fan triangles of a clipped primitive share a rank and follow each other as the fan
 // lists them) and their pixel boxes inside the tile worked out.  A wave then visits, in order,
 // only the entries whose box reaches its block: coverage, depth test Less with depth write,
@@ -904,74 +905,25 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
     const int32_t cx0 = tpx, cx1 = min(tpx + kTile - 1, (int32_t)a.g.width - 1);
     const int32_t cy0 = max(tpy, (int32_t)a.g.sy0), cy1 = min(tpy + kTile - 1, (int32_t)a.g.sy1 - 1);
 
-    // the tile's entries, region by region, with their sort keys
+    // The tile's entries lie in its five bin regions in the order they arrived; entry e of the
+    // regions taken one after the other:
     const uint32_t cnt[kBinRegions] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.y), (uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.x),
                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.w), (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.z),
                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)launch.y)}; // classes 0-3, late
     const uint32_t *bin = a.bins + (size_t)(view * a.g.n_tiles + tile) * a.bl.stride;
-    uint32_t n = 0;
-#pragma unroll
-    for (int r = 0; r < kBinRegions; ++r) {
-        for (uint32_t i = (uint32_t)tid; i < cnt[r]; i += kBlendThreads) {
-            const uint32_t rec = bin[a.bl.off[r] + i];
-            const uint32_t order = rec < a.n_slots ? rec : a.fan_order[rec - a.n_slots];
-            if (n + i < kBlendMaxEntries) s_key[n + i] = ((unsigned long long)order << 32) | rec;
-        }
-        n += cnt[r];
-    }
-    n = min(n, kBlendMaxEntries); // (k_finish has flagged the frame if a tile holds more)
-    uint32_t n_pow2 = 1;
-    while (n_pow2 < n) n_pow2 <<= 1;
-    for (uint32_t i = n + (uint32_t)tid; i < n_pow2; i += kBlendThreads) s_key[i] = ~0ull;
-    __syncthreads();
-    SXE_BSTAMP(4);
-    // Bitonic network.  Thread t takes elements t, t + 1024, ...: a step whose stride is below 64
-    // stays inside runs of 64 elements that one wave alone reads and writes, in program order, so
-    // only the steps with longer strides need the workgroup's barrier, before and after.
-    for (uint32_t k = 2; k <= n_pow2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64u) __syncthreads();
-            for (uint32_t i = (uint32_t)tid; i < n_pow2; i += kBlendThreads) {
-                const uint32_t partner = i ^ j;
-                if (partner > i) {
-                    const unsigned long long x = s_key[i], y = s_key[partner];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        s_key[i] = y;
-                        s_key[partner] = x;
-                    }
-                }
-            }
-            if (j >= 64u) {
-                __syncthreads();
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    __syncthreads();
-
-    SXE_BSTAMP(1);
-    // Every entry's pixel box inside the tile takes the place of its rank in the key: the order is
-    // settled, and the waves choose their entries by the box.
-    for (uint32_t i = (uint32_t)tid; i < n; i += kBlendThreads) {
-        const uint32_t rec = (uint32_t)s_key[i];
-        const RastRec r = a.rast[rec];
-        uint32_t box = kNoBox;
-        if (r.x0 != kNoRaster) {
-            const Tri t = unpack_tri(r, a.wide, rec);
-            int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
-            if (pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1))
-                box = (uint32_t)(bx0 - tpx) | ((uint32_t)(by0 - tpy) << 8) | ((uint32_t)(bx1 - tpx) << 16) | ((uint32_t)(by1 - tpy) << 24);
-        }
-        s_key[i] = ((unsigned long long)box << 32) | rec;
-    }
-    __syncthreads();
-
+    const uint32_t c1 = cnt[0], c2 = c1 + cnt[1], c3 = c2 + cnt[2], c4 = c3 + cnt[3], n_total = c4 + cnt[4];
+    const uint32_t r0 = a.bl.off[0], r1 = a.bl.off[1] - c1, r2 = a.bl.off[2] - c2, r3 = a.bl.off[3] - c3, r4 = a.bl.off[4] - c4;
+    const uint32_t n_slots = a.n_slots;
+    const uint32_t *fan_order = a.fan_order;
+#define SXE_ENTRY_AT(e, rec, order)                                                                      \
+    do {                                                                                                 \
+        rec = bin[(e) + ((e) < c1 ? r0 : (e) < c2 ? r1 : (e) < c3 ? r2 : (e) < c4 ? r3 : r4)];           \
+        order = rec < n_slots ? rec : fan_order[rec - n_slots]; /* a fan triangle ranks as its primitive does */ \
+    } while (0)
+    uint32_t n = 0; // entries of the piece being blended
     // The tile is 4x4 blocks of 8x8 pixels and every wave owns one: a small triangle reaches one or two waves.
     // Which wave owns which block turns by one column from one row of blocks to the next: waves 0, 4, 8, 12 share an
     // execution unit, and a crowded corner of the tile should not land on one unit alone.
-    // From here on the waves go their own ways, without a barrier, until the tile is written.
     const int32_t wy = wave >> 2, wx = (wave + wy) & 3;
     const int32_t tx = 8 * wx + (lane & 7), ty = 8 * wy + (lane >> 3); // in the tile
     const int32_t px = tpx + tx, py = tpy + ty;
@@ -1042,82 +994,207 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
         if (reaches) r = a.rast[(uint32_t)key];
     };
     const auto from_lane = [](float v, int from) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), from)); };
-    unsigned long long key_next = 0ull;
-    bool reaches_next = false;
-    RastRec r_next;
-    fetch(0u, key_next, reaches_next, r_next);
-    for (uint32_t base = 0; base < n; base += 64) {
-        const unsigned long long key = key_next;
-        const bool reaches = reaches_next;
-        const RastRec r = r_next;
-        if (base + 64 < n) fetch(base + 64, key_next, reaches_next, r_next);
-        unsigned long long todo = __ballot(reaches);
-        if (!todo) continue;
-        // A narrow triangle's biased edge functions (inside: all three >= 0) at pixel (x, y) of the
-        // tile are c + a x + b y; every term is exact in 32 bits, the values at the pixels of the
-        // triangle's box are the ones edge_start() gives, and a and b fit 24 bits.  A wide
-        // triangle keeps its first corner and offsets in (a0, b0, c0, a1) instead.
-        const uint32_t box_l = (uint32_t)(key >> 32);
-        int32_t a0 = r.x0, b0 = r.y0, c0 = (int32_t)r.d1, a1 = (int32_t)r.d2, b1 = 0, c1 = 0, a2 = 0, b2 = 0, c2 = 0;
-        uint32_t flags_l = kEdgeWide;
-        if (reaches && r.d1 != kWideTri) {
-            const Tri t = unpack_tri(r, a.wide, (uint32_t)key);
-            const int32_t ox = (int32_t)(box_l & 255u), oy = (int32_t)((box_l >> 8) & 255u);
-            const EdgeStart es = edge_start(t, tpx + ox, tpy + oy);
-            a0 = -256 * es.ey0; b0 = 256 * es.ex0; c0 = es.R0 - mul_narrow(a0, ox) - mul_narrow(b0, oy);
-            a1 = -256 * es.ey1; b1 = 256 * es.ex1; c1 = es.R1 - mul_narrow(a1, ox) - mul_narrow(b1, oy);
-            a2 = -256 * es.ey2; b2 = 256 * es.ex2; c2 = es.R2 - mul_narrow(a2, ox) - mul_narrow(b2, oy);
-            flags_l = (es.b1 ? kEdgeBias1 : 0u) | (es.b2 ? kEdgeBias2 : 0u);
-        }
-        while (todo) {
-            const int from = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t box = (uint32_t)__builtin_amdgcn_readlane((int)box_l, from);
-            const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)flags_l, from);
-            const int32_t A0 = __builtin_amdgcn_readlane(a0, from), B0 = __builtin_amdgcn_readlane(b0, from), C0 = __builtin_amdgcn_readlane(c0, from);
-            const int32_t A1 = __builtin_amdgcn_readlane(a1, from);
-            const float z0 = from_lane(r.z0, from), dz1 = from_lane(r.dz1, from), dz2 = from_lane(r.dz2, from), rA = from_lane(r.rA, from);
-            const bool in_box = (tx >= (int32_t)(box & 255u)) & (tx <= (int32_t)((box >> 16) & 255u)) & (ty >= (int32_t)((box >> 8) & 255u)) &
-                                (ty <= (int32_t)(box >> 24));
-            bool inside;
-            float l1, l2;
-            if (!(flags & kEdgeWide)) {
-                const int32_t B1 = __builtin_amdgcn_readlane(b1, from), C1 = __builtin_amdgcn_readlane(c1, from);
-                const int32_t A2 = __builtin_amdgcn_readlane(a2, from), B2 = __builtin_amdgcn_readlane(b2, from), C2 = __builtin_amdgcn_readlane(c2, from);
-                const int32_t E0 = mul_narrow(A0, tx) + (mul_narrow(B0, ty) + C0);
-                const int32_t E1 = mul_narrow(A1, tx) + (mul_narrow(B1, ty) + C1);
-                const int32_t E2 = mul_narrow(A2, tx) + (mul_narrow(B2, ty) + C2);
-                inside = (E0 | E1 | E2) >= 0;
-                l1 = (float)(E1 + (int32_t)(flags & kEdgeBias1)) * rA;
-                l2 = (float)(E2 + (int32_t)((flags >> 1) & 1u)) * rA;
-            } else {
-                // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 with the top-left rule as a bias
-                RastRec rw;
-                rw.x0 = A0; rw.y0 = B0; rw.d1 = (uint32_t)C0; rw.d2 = (uint32_t)A1;
-                const Tri t = unpack_tri(rw, a.wide, (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from));
-                const long long ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1, ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2, ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
-                const long long E0 = ex0 * ((long long)sy - t.y1) - ey0 * ((long long)sx - t.x1);
-                const long long E1 = ex1 * ((long long)sy - t.y2) - ey1 * ((long long)sx - t.x2);
-                const long long E2 = ex2 * ((long long)sy - t.y0) - ey2 * ((long long)sx - t.x0);
-                inside = ((E0 - edge_bias((int32_t)ex0, (int32_t)ey0)) | (E1 - edge_bias((int32_t)ex1, (int32_t)ey1)) |
-                          (E2 - edge_bias((int32_t)ex2, (int32_t)ey2))) >= 0;
-                l1 = (float)E1 * rA;
-                l2 = (float)E2 * rA;
-            }
-            const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
-            // below the cleared 1.0, and Comparison::Less against what is there (src/renderer/drawer.rs:700)
-            const bool want = in_box & inside & (z < 1.0f) & (z < depth);
-            if (!__ballot(want)) continue;
-            if (__ballot(want && pend)) blend_pending();
-            const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from);
-            if (want) {
-                depth = z;
-                pend = true;
-                pend_rec = rec;
-                pend_l1 = l1;
-                pend_l2 = l2;
+    // A tile with more entries than the sort holds is taken in pieces: the entries ranked
+    // first_order .. last_order, at most kBlendMaxEntries of them, are gathered, sorted and blended,
+    // then the next ranks, over what the pixels hold by then (depth, colour and the waiting
+    // fragments stay in their lanes).  Submission order is all that matters, and the pieces are
+    // consecutive stretches of it.
+    __shared__ uint32_t s_hist[64], s_fill;
+    uint32_t first_order = 0u;
+    for (;;) {
+        uint32_t last_order = 0xFFFFFFFFu;
+        if (n_total > kBlendMaxEntries) {
+            // The largest last_order such that at most kBlendMaxEntries entries rank in
+            // [first_order, last_order]: the ranks from `lo` on, `width` of them, are cut into up to
+            // 64 equal buckets and counted; the buckets that fit are taken whole and the search goes
+            // on inside the first one that does not, six bits of the rank per pass.
+            uint32_t lo = first_order, budget = kBlendMaxEntries;
+            unsigned long long width = 0x100000000ull - (unsigned long long)lo;
+            for (;;) {
+                uint32_t shift = 0;
+                while ((width >> shift) > 64ull) ++shift;
+                if (tid < 64) s_hist[tid] = 0u;
+                __syncthreads();
+                for (uint32_t e = (uint32_t)tid; e < n_total; e += kBlendThreads) {
+                    uint32_t rec, order;
+                    SXE_ENTRY_AT(e, rec, order);
+                    if (order >= lo && (unsigned long long)(order - lo) < width) atomicAdd(&s_hist[(order - lo) >> shift], 1u);
+                }
+                __syncthreads();
+                uint32_t fit = 0, b = 0;
+                for (; b < 64u; ++b) {
+                    const uint32_t k = s_hist[b];
+                    if (fit + k > budget) break;
+                    fit += k;
+                }
+                __syncthreads(); // (the counts are cleared again in the next pass)
+                if (b == 64u) { // everything from `lo` on fits
+                    last_order = (uint32_t)((unsigned long long)lo + width - 1ull);
+                    break;
+                }
+                budget -= fit;
+                lo += b << shift;
+                if (shift == 0u) {
+                    // rank `lo` alone does not fit any more: the piece ends before it.  (Entries of one rank
+                    // are the fan triangles of one clipped primitive, seven at most; should a rank ever
+                    // hold more than a whole piece, it is taken as far as the sort reaches.)
+                    last_order = lo > first_order ? lo - 1u : lo;
+                    break;
+                }
+                width = min(width - ((unsigned long long)b << shift), 1ull << shift);
             }
         }
+        // the piece's entries with their sort keys (rank, then record number)
+        if (tid == 0) s_fill = 0u;
+        __syncthreads();
+        for (uint32_t e0 = 0; e0 < n_total; e0 += kBlendThreads) {
+            const uint32_t e = e0 + (uint32_t)tid;
+            uint32_t rec = 0, order = 0;
+            bool take = false;
+            if (e < n_total) {
+                SXE_ENTRY_AT(e, rec, order);
+                take = order >= first_order && order <= last_order;
+            }
+            const unsigned long long takers = __ballot(take);
+            if (takers) { // one place in the list per wave and round
+                uint32_t at = 0;
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)takers) - 1);
+                if (lane == leader) at = atomicAdd(&s_fill, (uint32_t)__popcll(takers));
+                at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader) + (uint32_t)__popcll(takers & ((1ull << lane) - 1ull));
+                if (take && at < kBlendMaxEntries) s_key[at] = ((unsigned long long)order << 32) | rec;
+            }
+        }
+        __syncthreads();
+        n = min(s_fill, kBlendMaxEntries);
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t i = n + (uint32_t)tid; i < n_pow2; i += kBlendThreads) s_key[i] = ~0ull;
+        __syncthreads();
+        SXE_BSTAMP(4);
+        // Bitonic network.  Thread t takes elements t, t + 1024, ...: a step whose stride is below 64
+        // stays inside runs of 64 elements that one wave alone reads and writes, in program order, so
+        // only the steps with longer strides need the workgroup's barrier, before and after.
+        for (uint32_t k = 2; k <= n_pow2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64u) __syncthreads();
+                for (uint32_t i = (uint32_t)tid; i < n_pow2; i += kBlendThreads) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const unsigned long long x = s_key[i], y = s_key[partner];
+                        const bool up = (i & k) == 0;
+                        if ((x > y) == up) {
+                            s_key[i] = y;
+                            s_key[partner] = x;
+                        }
+                    }
+                }
+                if (j >= 64u) {
+                    __syncthreads();
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        __syncthreads();
+
+        SXE_BSTAMP(1);
+        // Every entry's pixel box inside the tile takes the place of its rank in the key: the order is
+        // settled, and the waves choose their entries by the box.
+        for (uint32_t i = (uint32_t)tid; i < n; i += kBlendThreads) {
+            const uint32_t rec = (uint32_t)s_key[i];
+            const RastRec r = a.rast[rec];
+            uint32_t box = kNoBox;
+            if (r.x0 != kNoRaster) {
+                const Tri t = unpack_tri(r, a.wide, rec);
+                int32_t bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+                if (pixel_box(t, cx0, cx1, cy0, cy1, bx0, bx1, by0, by1))
+                    box = (uint32_t)(bx0 - tpx) | ((uint32_t)(by0 - tpy) << 8) | ((uint32_t)(bx1 - tpx) << 16) | ((uint32_t)(by1 - tpy) << 24);
+            }
+            s_key[i] = ((unsigned long long)box << 32) | rec;
+        }
+        __syncthreads();
+
+        // From here on the waves go their own ways, without a barrier, until the piece is done.
+        unsigned long long key_next = 0ull;
+        bool reaches_next = false;
+        RastRec r_next;
+        fetch(0u, key_next, reaches_next, r_next);
+        for (uint32_t base = 0; base < n; base += 64) {
+            const unsigned long long key = key_next;
+            const bool reaches = reaches_next;
+            const RastRec r = r_next;
+            if (base + 64 < n) fetch(base + 64, key_next, reaches_next, r_next);
+            unsigned long long todo = __ballot(reaches);
+            if (!todo) continue;
+            // A narrow triangle's biased edge functions (inside: all three >= 0) at pixel (x, y) of the
+            // tile are c + a x + b y; every term is exact in 32 bits, the values at the pixels of the
+            // triangle's box are the ones edge_start() gives, and a and b fit 24 bits.  A wide
+            // triangle keeps its first corner and offsets in (a0, b0, c0, a1) instead.
+            const uint32_t box_l = (uint32_t)(key >> 32);
+            int32_t a0 = r.x0, b0 = r.y0, c0 = (int32_t)r.d1, a1 = (int32_t)r.d2, b1 = 0, c1 = 0, a2 = 0, b2 = 0, c2 = 0;
+            uint32_t flags_l = kEdgeWide;
+            if (reaches && r.d1 != kWideTri) {
+                const Tri t = unpack_tri(r, a.wide, (uint32_t)key);
+                const int32_t ox = (int32_t)(box_l & 255u), oy = (int32_t)((box_l >> 8) & 255u);
+                const EdgeStart es = edge_start(t, tpx + ox, tpy + oy);
+                a0 = -256 * es.ey0; b0 = 256 * es.ex0; c0 = es.R0 - mul_narrow(a0, ox) - mul_narrow(b0, oy);
+                a1 = -256 * es.ey1; b1 = 256 * es.ex1; c1 = es.R1 - mul_narrow(a1, ox) - mul_narrow(b1, oy);
+                a2 = -256 * es.ey2; b2 = 256 * es.ex2; c2 = es.R2 - mul_narrow(a2, ox) - mul_narrow(b2, oy);
+                flags_l = (es.b1 ? kEdgeBias1 : 0u) | (es.b2 ? kEdgeBias2 : 0u);
+            }
+            while (todo) {
+                const int from = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t box = (uint32_t)__builtin_amdgcn_readlane((int)box_l, from);
+                const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)flags_l, from);
+                const int32_t A0 = __builtin_amdgcn_readlane(a0, from), B0 = __builtin_amdgcn_readlane(b0, from), C0 = __builtin_amdgcn_readlane(c0, from);
+                const int32_t A1 = __builtin_amdgcn_readlane(a1, from);
+                const float z0 = from_lane(r.z0, from), dz1 = from_lane(r.dz1, from), dz2 = from_lane(r.dz2, from), rA = from_lane(r.rA, from);
+                const bool in_box = (tx >= (int32_t)(box & 255u)) & (tx <= (int32_t)((box >> 16) & 255u)) & (ty >= (int32_t)((box >> 8) & 255u)) &
+                                    (ty <= (int32_t)(box >> 24));
+                bool inside;
+                float l1, l2;
+                if (!(flags & kEdgeWide)) {
+                    const int32_t B1 = __builtin_amdgcn_readlane(b1, from), C1 = __builtin_amdgcn_readlane(c1, from);
+                    const int32_t A2 = __builtin_amdgcn_readlane(a2, from), B2 = __builtin_amdgcn_readlane(b2, from), C2 = __builtin_amdgcn_readlane(c2, from);
+                    const int32_t E0 = mul_narrow(A0, tx) + (mul_narrow(B0, ty) + C0);
+                    const int32_t E1 = mul_narrow(A1, tx) + (mul_narrow(B1, ty) + C1);
+                    const int32_t E2 = mul_narrow(A2, tx) + (mul_narrow(B2, ty) + C2);
+                    inside = (E0 | E1 | E2) >= 0;
+                    l1 = (float)(E1 + (int32_t)(flags & kEdgeBias1)) * rA;
+                    l2 = (float)(E2 + (int32_t)((flags >> 1) & 1u)) * rA;
+                } else {
+                    // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1 with the top-left rule as a bias
+                    RastRec rw;
+                    rw.x0 = A0; rw.y0 = B0; rw.d1 = (uint32_t)C0; rw.d2 = (uint32_t)A1;
+                    const Tri t = unpack_tri(rw, a.wide, (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from));
+                    const long long ex0 = t.x2 - t.x1, ey0 = t.y2 - t.y1, ex1 = t.x0 - t.x2, ey1 = t.y0 - t.y2, ex2 = t.x1 - t.x0, ey2 = t.y1 - t.y0;
+                    const long long E0 = ex0 * ((long long)sy - t.y1) - ey0 * ((long long)sx - t.x1);
+                    const long long E1 = ex1 * ((long long)sy - t.y2) - ey1 * ((long long)sx - t.x2);
+                    const long long E2 = ex2 * ((long long)sy - t.y0) - ey2 * ((long long)sx - t.x0);
+                    inside = ((E0 - edge_bias((int32_t)ex0, (int32_t)ey0)) | (E1 - edge_bias((int32_t)ex1, (int32_t)ey1)) |
+                              (E2 - edge_bias((int32_t)ex2, (int32_t)ey2))) >= 0;
+                    l1 = (float)E1 * rA;
+                    l2 = (float)E2 * rA;
+                }
+                const float z = clamp_depth((z0 + l1 * dz1) + l2 * dz2);
+                // below the cleared 1.0, and Comparison::Less against what is there (src/renderer/drawer.rs:700)
+                const bool want = in_box & inside & (z < 1.0f) & (z < depth);
+                if (!__ballot(want)) continue;
+                if (__ballot(want && pend)) blend_pending();
+                const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, from);
+                if (want) {
+                    depth = z;
+                    pend = true;
+                    pend_rec = rec;
+                    pend_l1 = l1;
+                    pend_l2 = l2;
+                }
+            }
+        }
+        if (last_order == 0xFFFFFFFFu) break;
+        first_order = last_order + 1u;
+        __syncthreads(); // every wave is done with this piece's list
     }
     blend_pending();
     // out through LDS (the sort keys are done with), so that the stores run along the rows
@@ -1138,6 +1215,7 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
     }
     SXE_BSTAMP(3);
 #undef SXE_BSTAMP
+#undef SXE_ENTRY_AT
 }
 
 hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s)

@@ -1032,7 +1032,7 @@ def test_translucent_textures_are_blended_in_submission_order(orc):
     assert len(np.unique(ref["color"][..., 3])) > 3 and ref["color"][0, 0, 3] == 64
 
 
-def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
+def test_translucent_views_and_tiles_beyond_one_sort_of_the_ordered_path(orc):
     from tests.util import soup_scene
     # a set of views with a translucent texture
     s = scenes.sphere_field_scene(20, 4, 5.0, (-14.0, -4.0), 160, 96, n_textures=2, tex_size=64, name="views")
@@ -1063,25 +1063,25 @@ def test_translucent_views_and_the_entry_limit_of_the_ordered_path(orc):
             got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
             assert 1024 < d.tile_counts().max() <= 4096
         assert_frames_equal(got, ref, what="crowded translucent tiles, %d triangles" % n)
-    # more than 4096 entries in a tile that needs ordering: refused, not rendered wrong
-    rng = np.random.default_rng(77)
-    n = 32000  # about 6000 surviving entries in each of the four tiles around the centre
-    tris = np.zeros((n, 3, 3), np.float32)
-    tris[..., :2] = rng.uniform(-0.2, 0.2, (n, 1, 2)) + rng.uniform(-0.03, 0.03, (n, 3, 2))
-    tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
-    dense = soup_scene(tris, width=128, height=128, textures=[scenes.translucent_texture(64, 2)])
-    with api.HipDrawer(128, 128) as d:
-        d.update_scene(dense)
-        d.update_camera_matrices(ident, ident)
-        d.draw(0)
-        with pytest.raises(api.SxeError) as e:
+    # more than 4096 entries in a tile that needs ordering: sorted and blended in consecutive
+    # stretches of the submission order (BlendState::ALPHA knows no such limit, drawer.rs:660-663);
+    # with clipped fans (several entries of one rank) and a second, larger crowd
+    for n, seed, spread in ((32000, 77, 0.2), (60000, 78, 0.12)):
+        rng = np.random.default_rng(seed)
+        tris = np.zeros((n, 3, 3), np.float32)
+        tris[..., :2] = rng.uniform(-spread, spread, (n, 1, 2)) + rng.uniform(-0.03, 0.03, (n, 3, 2))
+        tris[..., 2] = rng.uniform(0.1, 0.9, (n, 1))
+        tris[::97, :, 2] = rng.uniform(-0.4, 1.4, (len(tris[::97]), 3))  # some cross the near or the far plane
+        dense = soup_scene(tris, width=128, height=128, textures=[scenes.translucent_texture(64, 2)])
+        ref = orc.render(dense, ident[None], ident, ident, 128, 128)
+        with api.HipDrawer(128, 128, coverage=True) as d:
+            d.update_scene(dense)
+            d.update_camera_matrices(ident, ident)
+            d.draw(0)
             d.sync()
-        assert e.value.code == api.E_CAPACITY and "submission order" in str(e.value)
-        d.set_textures([scenes.checker_texture(64, 2)])  # the same scene with an opaque texture is fine
-        d.update_scene(soup_scene(tris, width=128, height=128, textures=[scenes.checker_texture(64, 2)]))
-        d.draw(0)
-        d.sync()
-        assert (d.read_depth(0) < 1.0).sum() > 100
+            got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+            assert d.tile_counts().max() > 4096 * (1 if n == 32000 else 2)
+        assert_frames_equal(got, ref, what="translucent tiles beyond one sort, %d triangles" % n)
 
 
 def test_ui_quad_layer(orc):
