@@ -5,7 +5,7 @@ O=$R/gpurun_out/exp_pmc; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for f in $R/exp/libsxe_*.so; do
   b=$(basename $f .so)
-  cp $f $R/renderer_amd/libsxe_hip.so
+  export SXE_LIB=$f
   timeout -s KILL 120 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE --output-format csv -d $O/$b -- python3 $R/tools/frames.py 3 6 > $O/$b.log 2>&1 || { tail -5 $O/$b.log; exit 1; }
 done
 cd $R && python3 - <<'PY'
