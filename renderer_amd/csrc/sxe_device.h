@@ -93,18 +93,30 @@ struct EdgeStart {
     int32_t R0, R1, R2;
 };
 
+// The same bias for an edge vector of a narrow triangle (components below 2^15 in magnitude): the
+// sign of ey * 65536 - ex decides (ey > 0, or ey == 0 and ex <= 0: not a top or left edge).
+__device__ inline int32_t edge_bias_narrow(int32_t ex, int32_t ey) { return 1 + (((int32_t)((uint32_t)ey << 16) - ex) >> 31); }
+
+// With (X, Y) the sample relative to corner 0 and d1, d2 the other corners relative to it, the
+// edge functions are E1 = dy2 X - dx2 Y (edge v2 -> v0), E2 = dx1 Y - dy1 X (edge v0 -> v1) and
+// E0 = area2 - E1 - E2: the same integers as ex (sy - oy) - ey (sx - ox) edge by edge, in fewer
+// operations.  Every factor is below 2^15 in magnitude for a narrow triangle and a sample of its box.
 __device__ inline EdgeStart edge_start(const Tri &t, int32_t i, int32_t j)
 {
     EdgeStart e;
-    e.ex0 = t.x2 - t.x1; e.ey0 = t.y2 - t.y1;
-    e.ex1 = t.x0 - t.x2; e.ey1 = t.y0 - t.y2;
-    e.ex2 = t.x1 - t.x0; e.ey2 = t.y1 - t.y0;
-    e.b1 = edge_bias(e.ex1, e.ey1);
-    e.b2 = edge_bias(e.ex2, e.ey2);
-    const int32_t sx = 256 * i + 128, sy = 256 * j + 128;
-    e.R0 = mul_narrow(e.ex0, sy - t.y1) - mul_narrow(e.ey0, sx - t.x1) - edge_bias(e.ex0, e.ey0);
-    e.R1 = mul_narrow(e.ex1, sy - t.y2) - mul_narrow(e.ey1, sx - t.x2) - e.b1;
-    e.R2 = mul_narrow(e.ex2, sy - t.y0) - mul_narrow(e.ey2, sx - t.x0) - e.b2;
+    const int32_t dx1 = t.x1 - t.x0, dy1 = t.y1 - t.y0, dx2 = t.x2 - t.x0, dy2 = t.y2 - t.y0;
+    e.ex0 = dx2 - dx1; e.ey0 = dy2 - dy1;
+    e.ex1 = -dx2; e.ey1 = -dy2;
+    e.ex2 = dx1; e.ey2 = dy1;
+    e.b1 = edge_bias_narrow(e.ex1, e.ey1);
+    e.b2 = edge_bias_narrow(e.ex2, e.ey2);
+    const int32_t X = 256 * i + 128 - t.x0, Y = 256 * j + 128 - t.y0;
+    const int32_t F1 = mul_narrow(dy2, X) - mul_narrow(dx2, Y);
+    const int32_t F2 = mul_narrow(dx1, Y) - mul_narrow(dy1, X);
+    const int32_t area2 = mul_narrow(dx1, dy2) - mul_narrow(dx2, dy1);
+    e.R0 = area2 - F1 - F2 - edge_bias_narrow(e.ex0, e.ey0);
+    e.R1 = F1 - e.b1;
+    e.R2 = F2 - e.b2;
     return e;
 }
 

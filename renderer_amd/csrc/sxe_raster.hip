@@ -427,9 +427,10 @@ __device__ inline PixelMid shade_begin(const RasterArgs &a, const PixelWork &w, 
     const float rA = __uint_as_float(h.fan_or_ra); // (of the fan triangle that was found, for a clipped one)
     float l1, l2;
     if (r.d1 != kWideTri) { // narrow: same integers as below, from full-rate 24-bit multiplies
-        const int32_t sx = 256 * px + 128, sy = 256 * py + 128;
-        const int32_t E1 = mul_narrow(t.x0 - t.x2, sy - t.y2) - mul_narrow(t.y0 - t.y2, sx - t.x2);
-        const int32_t E2 = mul_narrow(t.x1 - t.x0, sy - t.y0) - mul_narrow(t.y1 - t.y0, sx - t.x0);
+        // (the edge functions as edge_start() writes them: the sample and the corners relative to corner 0)
+        const int32_t X = 256 * px + 128 - t.x0, Y = 256 * py + 128 - t.y0;
+        const int32_t E1 = mul_narrow(t.y2 - t.y0, X) - mul_narrow(t.x2 - t.x0, Y);
+        const int32_t E2 = mul_narrow(t.x1 - t.x0, Y) - mul_narrow(t.y1 - t.y0, X);
         l1 = (float)E1 * rA;
         l2 = (float)E2 * rA;
     } else {
