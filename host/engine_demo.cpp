@@ -14,7 +14,7 @@
 // update_uniforms, update_camera, acquire_image, draw, present.  The last presented frame is
 // written out.
 #include "sxe_drawer.hpp"
-#include "sxe_jpeg.hpp"
+#include "sxe_png.hpp"
 
 #include <cstring>
 #include <fstream>
@@ -92,9 +92,9 @@ int main(int argc, char **argv)
             im.width = r.get<uint32_t>();
             im.height = r.get<uint32_t>();
             if (im.width == 0 && im.height == 0) {
-                // no texels in the scene file: the path names a JPEG file next to it, loaded the
-                // way TextureData::load does (image::open(path).to_rgba(), src/renderer/types.rs:158-188)
-                const Status st = load_jpeg(scene_dir + t.path, im);
+                // no texels in the scene file: the path names an image file next to it (JPEG or PNG),
+                // loaded the way TextureData::load does (image::open(path).to_rgba(), src/renderer/types.rs:158-188)
+                const Status st = load_image(scene_dir + t.path, im);
                 if (!st) throw std::runtime_error(st.error);
             } else {
                 im.rgba.resize((size_t)im.width * im.height * 4);

@@ -94,6 +94,99 @@ def build_jpeg_dump(tmp_path):
     return exe
 
 
+def build_image_dump(tmp_path):
+    """A small program around sxe_host::load_image: <file> <out.rgba>, prints width and height."""
+    src = tmp_path / "i.cpp"
+    src.write_text(
+        '#include "sxe_png.hpp"\n#include <iostream>\n'
+        'int main(int, char **argv) {\n'
+        '    sxe_host::Image im;\n'
+        '    const sxe_host::Status s = sxe_host::load_image(argv[1], im);\n'
+        '    if (!s) { std::cerr << s.error << "\\n"; return 1; }\n'
+        '    std::cout << im.width << " " << im.height << "\\n";\n'
+        '    std::ofstream(argv[2], std::ios::binary).write(reinterpret_cast<const char *>(im.rgba.data()), (std::streamsize)im.rgba.size());\n'
+        '    return 0;\n}\n')
+    exe = str(tmp_path / "i")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", os.path.join(ROOT, "renderer_amd"), "-lsxe_hip", "-Wl,-rpath," + os.path.join(ROOT, "renderer_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def test_png_loader_against_an_independent_decoder(tmp_path):
+    """include/sxe_png.hpp: every colour type and bit depth, palette and colour-key transparency,
+    interlaced files, stored / fixed / dynamic compression, against an independent decoder, bit for
+    bit (PNG is lossless; 16-bit samples keep their high byte); damaged files are refused with a
+    message.  load_image picks the decoder by the file's content, like image::open
+    (src/renderer/types.rs:161-170)."""
+    Image = pytest.importorskip("PIL.Image")
+    import struct
+    import zlib
+    exe = build_image_dump(tmp_path)
+    rng = np.random.default_rng(4)
+    w, h = 53, 31
+    y, x = np.mgrid[0:h, 0:w]
+    rgba = np.stack([(x * 5) % 256, (y * 8) % 256, ((x + y) * 3) % 256, np.where((x // 6 + y // 5) % 2, 255, (x * 4) % 256)], -1).astype(np.uint8)
+    rgba[::3, ::2, :3] = rng.integers(0, 256, rgba[::3, ::2, :3].shape)  # noise: every filter type gets chosen somewhere
+    cases = {}
+    cases["rgba8"] = (Image.fromarray(rgba, "RGBA"), {})
+    cases["rgb8"] = (Image.fromarray(rgba[..., :3].copy(), "RGB"), {})
+    cases["grey8"] = (Image.fromarray(rgba[..., 0].copy(), "L"), {})
+    cases["greyalpha8"] = (Image.fromarray(rgba[..., [0, 3]].copy(), "LA"), {})
+    cases["grey1"] = (Image.fromarray(rgba[..., 0].copy(), "L").point(lambda v: 255 if v > 127 else 0).convert("1"), {})
+    cases["palette8"] = (Image.fromarray(rgba[..., :3].copy(), "RGB").quantize(200), {})
+    cases["palette4_transparent"] = (Image.fromarray(rgba[..., :3].copy(), "RGB").quantize(13), {"transparency": bytes([0, 128, 255, 40])})
+    cases["rgb8_colour_key"] = (Image.fromarray((rgba[..., :3] // 64 * 64).copy(), "RGB"), {"transparency": (64, 128, 0)})
+    cases["grey16"] = (Image.fromarray((rgba[..., 0].astype(np.uint16) * 257 + 13), "I;16"), {})
+    cases["rgba8_interlaced_by_hand"] = None  # (written below: PIL does not write Adam7)
+    cases["stored"] = (Image.fromarray(rgba, "RGBA"), {"compress_level": 0})
+    cases["fixed_codes"] = (Image.fromarray(np.zeros((4, 5, 3), np.uint8) + 7, "RGB"), {"compress_level": 1})
+    cases["big_rgb"] = (Image.fromarray(rng.integers(0, 256, (300, 421, 3), dtype=np.uint8), "RGB"), {"compress_level": 9})
+    for name, case in cases.items():
+        path, out = str(tmp_path / (name + ".png")), str(tmp_path / (name + ".rgba"))
+        if case is None:
+            # Adam7: the seven reduced images one after the other, each with filter type 0 on every row
+            def chunk(kind, body):
+                return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+            raw = b""
+            for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+                sub = rgba[y0::dy, x0::dx]
+                if sub.size:
+                    raw += b"".join(b"\0" + row.tobytes() for row in sub)
+            open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 1)) +
+                                   chunk(b"IDAT", zlib.compress(raw)[:100]) + chunk(b"IDAT", zlib.compress(raw)[100:]) + chunk(b"IEND", b""))
+            want = rgba
+        else:
+            img, opts = case
+            img.save(path, "PNG", **opts)
+            ref = Image.open(path)
+            if name == "grey16":
+                g = (np.asarray(ref).astype(np.uint32) >> 8).astype(np.uint8)
+                want = np.stack([g, g, g, np.full_like(g, 255)], -1)
+            else:
+                want = np.asarray(ref.convert("RGBA"))
+        p = subprocess.run([exe, path, out], capture_output=True, text=True)
+        hh, ww = want.shape[:2]
+        assert p.returncode == 0 and p.stdout.split() == [str(ww), str(hh)], (name, p.stderr)
+        got = np.fromfile(out, np.uint8).reshape(hh, ww, 4)
+        assert np.array_equal(got, want), (name, int((got != want).sum()))
+    assert (np.fromfile(str(tmp_path / "palette4_transparent.rgba"), np.uint8).reshape(h, w, 4)[..., 3] < 255).any()
+    assert (np.fromfile(str(tmp_path / "rgb8_colour_key.rgba"), np.uint8).reshape(h, w, 4)[..., 3] == 0).any()
+    # a JPEG goes to the JPEG decoder whatever its name; damaged and foreign files are refused
+    jpg = str(tmp_path / "really_a_jpeg.png")
+    Image.fromarray(rgba[..., :3].copy(), "RGB").save(jpg, "JPEG", quality=90)
+    assert subprocess.run([exe, jpg, str(tmp_path / "x.rgba")], capture_output=True, text=True).returncode == 0
+    good = bytearray(open(str(tmp_path / "rgba8.png"), "rb").read())
+    for name, damage in (("crc", lambda b: b.__setitem__(len(b) // 2, b[len(b) // 2] ^ 0x10)), ("cut", lambda b: b.__delitem__(slice(len(b) - 30, len(b)))),
+                         ("text", lambda b: b.__setitem__(slice(0, len(b)), b"hello, this is no image at all"))):
+        bad = bytearray(good)
+        damage(bad)
+        path = str(tmp_path / ("bad_" + name + ".png"))
+        open(path, "wb").write(bytes(bad))
+        p = subprocess.run([exe, path, str(tmp_path / "x.rgba")], capture_output=True, text=True)
+        assert p.returncode == 1 and ("png:" in p.stderr or "neither" in p.stderr), (name, p.stderr)
+
+
 def test_jpeg_loader_against_an_independent_decoder(tmp_path):
     """include/sxe_jpeg.hpp (the texture-file loader): baseline files in the usual samplings, with
     and without restart markers, decode to what an independent decoder gives, up to the few code
@@ -213,3 +306,38 @@ def test_textures_loaded_from_jpeg_files_end_to_end(tmp_path, orc):
     assert np.array_equal(got, ref["color"])
     with_original = orc.render(s, orc.to_model(s.transforms), view, proj, w, h)
     assert not np.array_equal(got, with_original["color"])
+
+
+@pytest.mark.gpu
+def test_textures_loaded_from_png_files_with_alpha_end_to_end(tmp_path, orc):
+    """A texture file with an alpha channel (a PNG: image::open(path).to_rgba() keeps the alpha,
+    src/renderer/types.rs:161-170) end to end: the C++ host loads it (sxe_host::load_image), the
+    frame takes the ordered blending path (BlendState::ALPHA, src/renderer/drawer.rs:660-663) and
+    must equal the oracle's frame of the same scene with the same texels.  One of the three textures
+    stays a JPEG: the loader goes by content."""
+    Image = pytest.importorskip("PIL.Image")
+    s = scenes.reference_demo_scene(n=64, seed=7, width=320, height=240)
+    s.textures = [s.textures[0], scenes.translucent_texture(128, 5), scenes.translucent_texture(64, 6)]
+    names = ["a.jpg", "b.png", "c.png"]
+    Image.fromarray(s.textures[0][..., :3]).save(str(tmp_path / names[0]), "JPEG", quality=90)
+    Image.fromarray(s.textures[1], "RGBA").save(str(tmp_path / names[1]), "PNG")
+    Image.fromarray(s.textures[2], "RGBA").quantize(64).save(str(tmp_path / names[2]), "PNG")  # palette with transparency
+    texels = [np.asarray(Image.open(str(tmp_path / n)).convert("RGBA")) for n in names]
+    assert np.array_equal(texels[1], s.textures[1]) and (texels[2][..., 3] < 255).any()
+    exe = build_jpeg_dump(tmp_path)  # (the JPEG's texels as this build's own decoder gives them)
+    p = subprocess.run([exe, str(tmp_path / names[0]), str(tmp_path / "a.rgba")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    texels[0] = np.fromfile(str(tmp_path / "a.rgba"), np.uint8).reshape(texels[0].shape)
+    p, out, _ = run_demo(tmp_path, s, n_images=2, n_frames=1, texture_files=names)
+    assert p.returncode == 0, p.stderr
+    w, h = s.size
+    got = np.fromfile(out, dtype=np.uint8).reshape(h, w, 4)
+    decoded = scenes.Scene(s.vertices, s.indices, s.meshes, s.objects, s.transforms, texels, camera=s.camera, size=s.size)
+    view, proj = orc.camera(s.camera, w, h)
+    ref = orc.render(decoded, orc.to_model(s.transforms), view, proj, w, h)
+    assert np.array_equal(got, ref["color"])
+    opaque = [t.copy() for t in texels]
+    for t in opaque:
+        t[..., 3] = 255
+    decoded.textures = opaque
+    assert not np.array_equal(got, orc.render(decoded, orc.to_model(s.transforms), view, proj, w, h)["color"])  # (the alpha mattered)
