@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-frames", type=int, default=512,
+                    help="untimed steps before the warm-up steps, so that the GPU's clocks have ramped up (0: none)")
     ap.add_argument("--check", action="store_true", help="compare the last frame with the oracle (slow)")
     ap.add_argument("--bands", choices=["auto", "even"], default="auto",
                     help="sortfirst: band heights evened out against the measured gather (auto) or equal")
@@ -240,8 +242,15 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
+    # Clocks first: a GPU that has been idle runs its first tens of milliseconds below its sustained
+    # clocks (the same 20 steps take 7 % longer after 5 frames of load than after 500), so the same
+    # step runs untimed --prewarm-frames times before the --warmup steps.  Neither is in the timed region.
+    prewarm_frames = max(0, args.prewarm_frames)  # (a count, not a time: every rank must take the same number of steps)
+    for i in range(prewarm_frames):
         step(i)
+    fence()
+    for i in range(args.warmup):
+        step(prewarm_frames + i)
     fence()
     redraws_before = drawer.stats()["redraws"]
     # The headline: exactly --steps steps between two fences, without any timing event on the
@@ -251,7 +260,7 @@ def main():
     for i in range(args.steps):
         # frames are enqueued back to back (the library keeps up to three in flight on its
         # stream); nothing waits on the host until the closing fence
-        step(args.warmup + i)
+        step(prewarm_frames + args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
     redraws_timed = drawer.stats()["redraws"] - redraws_before
@@ -259,7 +268,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    next_step = args.warmup + args.steps
+    next_step = prewarm_frames + args.warmup + args.steps
     # Per-kernel device times come from a pass of their own after the headline: the same step, every
     # kernel of every frame bracketed by HIP events the library records on its own stream.
     sampled_frames = 16
@@ -374,6 +383,8 @@ def main():
                           "value": n_prims * frames_per_step * sustained_steps / sustained_elapsed, "unit": "triangles/s"},
             "frame_stats": stats,
             "redraws_in_timed_region": redraws_timed,
+            "prewarm": {"frames": prewarm_frames,
+                        "why": "untimed frames before the --warmup steps so that the timed steps run at sustained clocks"},
         }
         if gather_ms is not None:
             result["gather_ms"] = gather_ms

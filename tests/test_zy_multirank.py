@@ -25,7 +25,7 @@ def test_sort_first_bench_with_ranks_sharing_one_gpu(world, config):
     env = dict(os.environ, SXE_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--config", str(config), "--scale", "0.25", "--check"]
+           "--config", str(config), "--scale", "0.25", "--prewarm-frames", "8", "--check"]
     run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-2000:]
     line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
