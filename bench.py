@@ -212,7 +212,8 @@ def main():
             drawer = make_drawer(scissor)
         else:
             first_frame = 12  # (the rotation system goes on where the trial frames left it)
-    pipe = shard.SortFirstPipeline(drawer, height, width, world, rank, weights=weights) if sortfirst else None
+    # (strict=False: frames drawn again after their bands had left are counted, and reported for the timed region)
+    pipe = shard.SortFirstPipeline(drawer, height, width, world, rank, weights=weights, strict=False) if sortfirst else None
 
     frame_no = [first_frame]
 
@@ -253,6 +254,7 @@ def main():
         step(prewarm_frames + i)
     fence()
     redraws_before = drawer.stats()["redraws"]
+    stale_before = pipe.stale_frames if pipe else 0
     # The headline: exactly --steps steps between two fences, without any timing event on the
     # stream (every event costs a few microseconds of stream time, six of them per frame).
     drawer.set_timing_stride(0)
@@ -264,6 +266,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     redraws_timed = drawer.stats()["redraws"] - redraws_before
+    stale_timed = (pipe.stale_frames - stale_before) if pipe else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=stat_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -388,6 +391,7 @@ def main():
         }
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
+            result["stale_bands_in_timed_region"] = stale_timed  # (frames drawn again after their bands had been gathered)
         if sortfirst:
             result["bands"] = shard.all_bands(height, world, weights=weights)
         if tuning is not None:

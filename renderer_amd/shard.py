@@ -148,6 +148,10 @@ def frame_hash(color):
     return int(((a + np.uint64(1)) * (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))).sum(dtype=np.uint64))
 
 
+class StaleBand(RuntimeError):
+    """Frames were drawn again after their bands had been gathered: the assembled frames are not final."""
+
+
 class SortFirstPipeline:
     """Sort-first rendering of a frame sequence on one rank: this rank's band of frame i is drawn
     into image i % 2 on the drawer's own stream while the band of frame i - 1 is being gathered on
@@ -155,13 +159,17 @@ class SortFirstPipeline:
 
     The drawer must have been created with this rank's scissor band (band_rows with the same
     `weights`) and at least two images.
-    Frames that overflow a work buffer are drawn again by the library when it takes their result,
-    which is after their band was sent: call `drawer.sync()` and check `stats()["redraws"]` when
-    that matters (it cannot happen once the buffers have grown to the scene).
+    A frame that overflows a work buffer is drawn again by the library when it takes the frame's
+    result, which is after its band was sent: the band that left was incomplete.  It cannot happen
+    once the buffers have grown to the scene (draw a frame and `sync()` before pipelining), and when
+    it does happen it is not silent: `finish()` raises `StaleBand` (with `strict=False` it records
+    the count in `stale_frames` instead), and the caller submits those frames again.
     """
 
-    def __init__(self, drawer, height, width, world, rank, dst=0, group=None, weights=None):
+    def __init__(self, drawer, height, width, world, rank, dst=0, group=None, weights=None, strict=True):
         import torch
+        self.strict, self.stale_frames = strict, 0
+        self._redraws_seen = drawer.stats()["redraws"]
         self.d, self.h, self.w, self.world, self.rank, self.dst, self.group = drawer, height, width, world, rank, dst, group
         self.weights = weights
         self.y0, self.y1 = band_rows(height, world, rank, weights=weights)
@@ -194,6 +202,15 @@ class SortFirstPipeline:
         """Wait for everything submitted; returns the last frame on `dst` (else None)."""
         self.d.sync()
         self.side.synchronize()
+        redraws = self.d.stats()["redraws"]
+        if redraws != self._redraws_seen:
+            # the library drew frames again (after growing a work buffer) when it took their results:
+            # by then their bands had been sent as they were
+            stale, self._redraws_seen = redraws - self._redraws_seen, redraws
+            self.stale_frames += stale
+            if self.strict:
+                raise StaleBand("%d frame(s) were drawn again after their bands had left rank %d: draw one frame and sync() "
+                                "before pipelining, or submit the frames again" % (stale, self.rank))
         return self.frame
 
     def last_gather_ms(self, i):

@@ -962,9 +962,34 @@ def test_sort_first_pipeline_on_one_rank(orc):
     w, h = s.size
     view, proj = orc.camera(s.camera, w, h)
     t = s.transforms.copy()
+    # frames that outgrow the first work buffers are drawn again when their results are taken,
+    # after their bands have left: the pipeline says so instead of handing out a stale frame
+    from tests.util import soup_scene
+    rng = np.random.default_rng(9)
+    tris = np.zeros((3000, 3, 3), np.float32)
+    tris[..., :2] = rng.uniform(-1, 1, (3000, 3, 2))
+    tris[..., 2] = rng.uniform(0.1, 0.9, (3000, 1))
+    crowd = soup_scene(tris, width=512, height=512)
+    with api.HipDrawer(512, 512, n_images=2) as d:
+        d.update_scene(crowd)
+        d.update_camera_matrices(IDENT, IDENT)
+        pipe = shard.SortFirstPipeline(d, 512, 512, 1, 0)
+        pipe.submit(0)
+        pipe.submit(1)
+        assert d.stats()["redraws"] == 0
+        with pytest.raises(shard.StaleBand):
+            pipe.finish()
+        assert pipe.stale_frames >= 1 and d.stats()["redraws"] == pipe.stale_frames
+        pipe = shard.SortFirstPipeline(d, 512, 512, 1, 0)  # (the buffers have grown: the same again is fine)
+        pipe.submit(0)
+        frame = pipe.finish()
+        assert np.array_equal(frame.cpu().numpy(), orc.render(crowd, IDENT[None], IDENT, IDENT, 512, 512)["color"])
     with api.HipDrawer(w, h, n_images=2) as d:
         d.update_scene(s)
         d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        # the buffers have grown to the scene now: nothing is drawn twice from here on
         pipe = shard.SortFirstPipeline(d, h, w, 1, 0)
         n = 7
         for f in range(n):
@@ -972,6 +997,7 @@ def test_sort_first_pipeline_on_one_rank(orc):
             orc.rotation_system(t, 3, f, 400.0)
             pipe.submit(f)
         frame = pipe.finish()
+        assert pipe.stale_frames == 0
         assert pipe.last_gather_ms(n - 1) >= 0.0
         ref = orc.render(s, orc.to_model(t), view, proj, w, h)
         assert np.array_equal(frame.cpu().numpy(), ref["color"])
