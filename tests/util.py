@@ -19,10 +19,11 @@ def render_oracle(orc, scene, width=None, height=None, models=None, view=None, p
 
 
 def render_hip(scene, width=None, height=None, models=None, view=None, proj=None, shading=0, scissor=None,
-               want_clip=False, use_drawables=False, image=0, light=None):
+               want_clip=False, use_drawables=False, image=0, light=None, reference_indexing=False, bgra=False):
     width = width or scene.size[0]
     height = height or scene.size[1]
-    with api.HipDrawer(width, height, coverage=True, shading=shading, scissor=scissor) as d:
+    with api.HipDrawer(width, height, coverage=True, shading=shading, scissor=scissor, reference_indexing=reference_indexing,
+                       bgra=bgra) as d:
         if use_drawables:
             d.set_textures(scene.textures)
             d.update_drawables(scene.drawables())

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Development: many random scenes, HIP frame against the oracle's, bit for bit (colour, depth,
 primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode (the lit extension under random lights among them),
-random scissor band, several objects and textures; sphere fields under random cameras.
+random scissor band, several objects and textures, some objects not rendered, the draw list of the reference
+binary (SXE_FLAG_COMPAT_REFERENCE_INDEXING) and the BGRA target order now and then, through either upload entry
+point; sphere fields under random cameras.
 
   fuzz_parity.py [cases] [seed]          (FUZZ_BIG=1: the soups' frames seven times as wide and high)
 """
@@ -77,8 +79,16 @@ def one_case(seed, case, verbose):
     if shading == 3 and rng.random() < 0.7:  # (the lit extension: else under the default light)
         light = dict(to_light=rng.normal(size=3).tolist(), to_viewer=rng.normal(size=3).tolist(), ambient=float(rng.uniform(0, 0.5)),
                      diffuse=float(rng.uniform(0, 1.2)), specular=float(rng.uniform(0, 1)), shininess_log2=int(rng.integers(0, 9)))
-    ref = oracle.render(s, models, view, proj, w, h, shading=shading, scissor=scissor, threads=8, light=light)
-    got = render_hip(s, models=models, view=view, proj=proj, shading=shading, scissor=scissor, light=light)
+    # the draw list as the reference binary records it (objects not rendered, texture groups, index
+    # ranges that run over several objects' meshes), and the other byte order of the target
+    compat, bgra = bool(rng.random() < 0.25), bool(rng.random() < 0.2)
+    if compat or rng.random() < 0.15:
+        s.objects["rendered"] = (rng.random(len(s.objects)) < 0.75).astype(np.uint32)
+    flags = (oracle.FLAG_REFERENCE_INDEXING if compat else 0) | (oracle.FLAG_BGRA if bgra else 0)
+    desc += " compat" * compat + " bgra" * bgra
+    ref = oracle.render(s, models, view, proj, w, h, shading=shading, scissor=scissor, threads=8, light=light, flags=flags)
+    got = render_hip(s, models=models, view=view, proj=proj, shading=shading, scissor=scissor, light=light,
+                     reference_indexing=compat, bgra=bgra, use_drawables=bool(rng.random() < 0.3))
     y0, y1 = scissor if scissor else (0, h)
     ok = (np.array_equal(ref["color"][y0:y1], got["color"][y0:y1]) and
           np.array_equal(ref["depth"][y0:y1].view(np.uint32), got["depth"][y0:y1].view(np.uint32)) and
