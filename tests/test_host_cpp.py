@@ -190,8 +190,8 @@ def test_png_loader_against_an_independent_decoder(tmp_path):
 def test_jpeg_loader_against_an_independent_decoder(tmp_path):
     """include/sxe_jpeg.hpp (the texture-file loader): baseline files in the usual samplings, with
     and without restart markers, decode to what an independent decoder gives, up to the few code
-    values by which integer inverse DCTs and chroma interpolation differ; progressive files are
-    refused.  The test images are synthetic (the reference's textures are unavailable LFS pointers)."""
+    values by which integer inverse DCTs and chroma interpolation differ; progressive files
+    likewise; lossless ones are refused.  The test images are synthetic (the reference's textures are unavailable LFS pointers)."""
     Image = pytest.importorskip("PIL.Image")
     exe = build_jpeg_dump(tmp_path)
     rng = np.random.default_rng(1)
@@ -227,10 +227,31 @@ def test_jpeg_loader_against_an_independent_decoder(tmp_path):
     p = subprocess.run([exe, str(tmp_path / "grey22.jpg"), str(tmp_path / "grey22.rgba")], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert open(str(tmp_path / "grey22.rgba"), "rb").read() == open(str(tmp_path / "grey.rgba"), "rb").read()
-    path = str(tmp_path / "progressive.jpg")
-    Image.fromarray(picture(40, 40)).save(path, "JPEG", progressive=True)
-    p = subprocess.run([exe, path, str(tmp_path / "x.rgba")], capture_output=True, text=True)
-    assert p.returncode == 1 and "baseline only" in p.stderr
+    # progressive files (spectral selection and successive approximation, T.81 annex G: what the
+    # image crate's decoder reads as well), in the same samplings
+    for name, opts, (w, h), max_diff, mean_diff in [("p444", dict(subsampling=0, quality=90), (67, 45), 3, 0.1),
+                                                    ("p420", dict(subsampling=2, quality=85), (130, 77), 12, 1.5),
+                                                    ("p422", dict(subsampling=1, quality=60), (75, 64), 12, 1.5),
+                                                    ("pgrey", dict(quality=80), (50, 33), 3, 0.1),
+                                                    ("pbig", dict(subsampling=2, quality=95), (301, 203), 12, 1.5)]:
+        img = Image.fromarray(picture(w, h))
+        if name == "pgrey":
+            img = img.convert("L")
+        path, out = str(tmp_path / (name + ".jpg")), str(tmp_path / (name + ".rgba"))
+        img.save(path, "JPEG", progressive=True, **opts)
+        assert b"\xff\xc2" in open(path, "rb").read()[:1000]  # (a progressive frame header)
+        p = subprocess.run([exe, path, out], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.split() == [str(w), str(h)], (name, p.stderr)
+        got = np.fromfile(out, np.uint8).reshape(h, w, 4)
+        ref = np.asarray(Image.open(path).convert("RGBA"))
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert (got[..., 3] == 255).all() and d.max() <= max_diff and d.mean() <= mean_diff, (name, d.max(), d.mean())
+    # a lossless frame header (SOF3) is refused by name
+    raw = bytearray(open(str(tmp_path / "444.jpg"), "rb").read())
+    raw[raw.find(b"\xff\xc0") + 1] = 0xC3
+    (tmp_path / "lossless.jpg").write_bytes(bytes(raw))
+    p = subprocess.run([exe, str(tmp_path / "lossless.jpg"), str(tmp_path / "x.rgba")], capture_output=True, text=True)
+    assert p.returncode == 1 and "lossless" in p.stderr
     (tmp_path / "junk.jpg").write_bytes(b"\xff\xd8\xff\xdb\x00\x03\x00")
     p = subprocess.run([exe, str(tmp_path / "junk.jpg"), str(tmp_path / "x.rgba")], capture_output=True, text=True)
     assert p.returncode == 1 and "jpeg:" in p.stderr
