@@ -129,7 +129,14 @@ def test_noalloc_calls_that_overlap_on_one_gpu_are_refused_not_raced():
             t.join()
         for o in outcome:
             assert not o["bad"], o["bad"][:3]
-            assert o["ok"] >= 1 and o["ok"] + o["busy"] == 40
+            assert o["ok"] + o["busy"] == 40
+        # (one thread may lose every race; some call went through, and with the other thread gone
+        # every context's call does)
+        assert sum(o["ok"] for o in outcome) >= 1
+        for d, ref in ctxs:
+            d.draw_noalloc(1)
+            got = _images(d, 1)
+            assert np.array_equal(got["color"], ref["color"]) and np.array_equal(got["depth"], ref["depth"])
     finally:
         for d, _ in ctxs:
             d.close()

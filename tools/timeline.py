@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Development probe: per-tile workgroup phase clocks of k_raster_shade (config 3)."""
+"""Development probe: per-tile workgroup phase clocks of k_raster_shade.
+
+  timeline.py [config] [world rank]     (world, rank: only that rank's band of a sort-first split)
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from renderer_amd import api, scenes
+from renderer_amd import api, scenes, shard
 s = scenes.config_scene(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 w, h = s.size
-with api.HipDrawer(w, h, timing=True, debug_flags=(1 << 26)) as d:
+band = shard.band_rows(h, int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None
+with api.HipDrawer(w, h, timing=True, debug_flags=(1 << 26), scissor=band) as d:
     d.update_scene(s); d.update_camera(s.camera)
     for i in range(3):
         d.rotation_system(3, i, 16.0); d.draw(0); d.sync()
