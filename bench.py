@@ -93,7 +93,19 @@ def cpu_baseline(scene, width, height, n_prims):
         dt = time.perf_counter() - t0
         if dt > 12.0 or frames >= 64:
             break
+    # config 1 (the reference's own CPU-runnable case: one cube, 800x600) on one thread
+    from renderer_amd import scenes as _scenes
+    cube = _scenes.config_scene(1)
+    cw, ch = cube.size
+    cview, cproj = oracle.camera(cube.camera, cw, ch)
+    cmodels = oracle.to_model(cube.transforms)
+    oracle.render(cube, cmodels, cview, cproj, cw, ch, threads=1)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        oracle.render(cube, cmodels, cview, cproj, cw, ch, threads=1)
+    cube_ms = 1e3 * (time.perf_counter() - t1) / 5.0
     return {"value": n_prims * frames / dt, "unit": "triangles/s", "cores": cores, "kind": "port",
+            "config1_single_thread_ms_per_frame": cube_ms,
             "cpu": cpu_model(), "cpus_visible": os.cpu_count(),
             "sample": "%d step(s) of the same workload (rotation update, model matrices, one full frame each), %.1f s "
                       "of CPU work, band-parallel oracle with %d threads (this job's share of the host: "
