@@ -2,6 +2,7 @@
 (src/renderer/drawer.rs:26-31, src/main.rs:140-199) driven from C++ through the C ABI."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -362,3 +363,13 @@ def test_textures_loaded_from_png_files_with_alpha_end_to_end(tmp_path, orc):
         t[..., 3] = 255
     decoded.textures = opaque
     assert not np.array_equal(got, orc.render(decoded, orc.to_model(s.transforms), view, proj, w, h)["color"])  # (the alpha mattered)
+
+
+def test_damaged_texture_files_under_host_sanitizers():
+    """tools/fuzz_image_loaders.py: mutated PNG and JPEG files of every kind the loaders read are
+    either decoded or refused with a message, under -fsanitize=address,undefined (host code only)."""
+    pytest.importorskip("PIL.Image")
+    tool = os.path.join(ROOT, "tools", "fuzz_image_loaders.py")
+    run = subprocess.run([sys.executable, tool, "25", "7"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    assert "prog420.jpg" in run.stdout and "FAILED" not in run.stdout
