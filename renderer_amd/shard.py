@@ -6,7 +6,8 @@ src/renderer/drawer.rs:426-454).  The split follows the two ways its frame decom
 * sort-first: the framebuffer is cut into horizontal bands of whole tile rows, one band per rank;
   geometry is replicated, bands are pixel-disjoint, so the only exchange is the final gather of
   the finished RGBA8 rows (grouped send/receive: RCCL over xGMI when the backend is "nccl", gloo
-  on CPU), overlapped with the drawing of the next frame (SortFirstPipeline);
+  on CPU), overlapped with the drawing of the next frame (SortFirstPipeline); exchange_bands leaves
+  the whole frame on every rank instead;
 * frame-parallel: independent views are dealt to ranks in contiguous blocks; no exchange at all.
 """
 import numpy as np
@@ -120,6 +121,44 @@ def gather_bands(band, height, width, world, rank, dst=0, group=None, out=None, 
             w.wait()
     if via_host:
         for r, a, b in senders:
+            frame[a:b].copy_(landing[r])
+    return frame
+
+
+def exchange_bands(band, height, width, world, rank, group=None, out=None, weights=None):
+    """Every rank ends up with the whole frame (a consumer on each GPU: a post-process, an encoder per
+    GPU): each rank sends its band to every other rank and receives theirs, all as one group of
+    point-to-point operations, every band at its own size, straight into its rows of `out`.
+    gather_bands is the cheaper exchange when one rank presents the frame; this one moves
+    (world - 1) times as many bytes, every rank's own band over each of its links.
+    Arguments as for gather_bands; returns the assembled (height, width, 4) uint8 tensor on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    bands = all_bands(height, world, weights=weights)
+    y0, y1 = bands[rank]
+    if tuple(band.shape) != (y1 - y0, width, 4) or band.dtype != torch.uint8:
+        raise ValueError("band has shape %s, expected %s uint8" % (tuple(band.shape), (y1 - y0, width, 4)))
+    band = band.contiguous()
+    frame = out if out is not None else torch.empty((height, width, 4), dtype=torch.uint8, device=band.device)
+    if tuple(frame.shape) != (height, width, 4) or frame.dtype != torch.uint8 or not frame.is_contiguous():
+        raise ValueError("out must be a contiguous (%d, %d, 4) uint8 tensor" % (height, width))
+    if y1 > y0:
+        frame[y0:y1].copy_(band)
+    if world == 1:
+        return frame
+    via_host = band.is_cuda and dist.get_backend(group) == "gloo"
+    others = [(r, a, b) for r, (a, b) in enumerate(bands) if r != rank and b > a]
+    landing = {r: (torch.empty((b - a, width, 4), dtype=torch.uint8) if via_host else frame[a:b]) for r, a, b in others}
+    mine = band.cpu() if via_host else band
+    ops = [dist.P2POp(dist.irecv, landing[r], r, group) for r, a, b in others]
+    if y1 > y0:
+        ops += [dist.P2POp(dist.isend, mine, r, group) for r in range(world) if r != rank]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if via_host:
+        for r, a, b in others:
             frame[a:b].copy_(landing[r])
     return frame
 

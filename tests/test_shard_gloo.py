@@ -104,6 +104,12 @@ def _worker(rank, world, port, out_path):
     b0, b1 = sh.band_rows(h, world, rank, weights=wts)
     wband = oracle.render(s, models, view, proj, w, h, scissor=(b0, b1))["color"][b0:b1]
     weighted = sh.gather_bands(torch.from_numpy(np.ascontiguousarray(wband)), h, w, world, rank, weights=wts)
+    # the whole frame on every rank, equal and weighted bands
+    everywhere = sh.exchange_bands(torch.from_numpy(np.ascontiguousarray(band)), h, w, world, rank)
+    everywhere_w = sh.exchange_bands(torch.from_numpy(np.ascontiguousarray(wband)), h, w, world, rank, weights=wts,
+                                     out=torch.zeros((h, w, 4), dtype=torch.uint8))
+    full_here = oracle.render(s, models, view, proj, w, h)["color"]
+    assert np.array_equal(everywhere.numpy(), full_here) and np.array_equal(everywhere_w.numpy(), full_here)
     # frame-parallel bookkeeping: max-over-ranks timing as bench.py does it
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
