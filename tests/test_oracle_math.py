@@ -78,7 +78,7 @@ def test_model_matrix_is_T_R_S(orc):
 
 
 def test_projection_known_answers(orc):
-    # Appendix-D constants of the survey: cot(22.5 deg) = 2.41421356...
+    # closed-form constants: cot(22.5 deg) = 2.41421356...
     p43 = orc.perspective(45.0, 800.0 / 600.0, 0.1, 1000.0).reshape(4, 4)
     assert p43[0][0] == pytest.approx(1.81066, abs=2e-6)
     assert p43[1][1] == pytest.approx(-2.41421342, abs=5e-7)  # Y flip only (drawer.rs:255)
@@ -118,7 +118,7 @@ def test_view_matrix(orc):
 
 
 def test_cube_corner_known_answers(orc):
-    """Corners of Cube::new under model = T(0,0,-3), view = I, 800x600 (survey appendix D)."""
+    """Corners of Cube::new under model = T(0,0,-3), view = I, 800x600 (closed forms worked out by hand from the cited formulas)."""
     from renderer_amd import scenes
     s = scenes.cube_scene()
     t = orc.identity_transforms(1)
