@@ -210,6 +210,28 @@ def test_tiny_textures_and_coordinates_beyond_the_edges(orc):
     assert_frames_equal(got, ref, what="tiny textures")
 
 
+def test_textures_of_the_largest_extent(orc):
+    """Rows and columns of 16384 texels, the most a texture may have: footprint addressing at the far
+    end of a table (24-bit row multiply), the clamp there, and the refusal of one texel more."""
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(78)
+    sizes = [(16384, 1), (1, 16384), (16384, 3), (2, 16384)]
+    textures = [rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) for (w, h) in sizes]
+    for t in textures:
+        t[..., 3] = 255
+    n_obj, per = len(sizes), 120
+    tris = random_soup(rng, n_obj * per, 160, 120, kinds=("small", "medium", "large", "huge"))
+    uvs = rng.uniform(-0.1, 1.1, size=(n_obj * per * 3, 2)).astype(np.float32)
+    uvs[::5] = rng.choice(np.array([0.0, 1.0, 0.99999, 0.5], np.float32), size=uvs[::5].shape)
+    s = soup_scene(tris, uvs=uvs, textures=textures, width=160, height=120, objects_split=[per] * n_obj,
+                   tex_ids=np.arange(n_obj))
+    ref, got = _soup_pair(orc, s)
+    assert_frames_equal(got, ref, what="largest textures")
+    with api.HipDrawer(64, 64) as d:
+        with pytest.raises(api.SxeError):
+            d.set_textures([np.full((1, 16385, 4), 255, np.uint8)])
+
+
 def test_random_scenes(orc):
     """A hundred random scenes (tools/fuzz_parity.py: soups of every awkward kind at odd frame sizes,
     random shading mode, scissor band, object split, tiny textures, some translucent; sphere fields
