@@ -26,6 +26,7 @@ FLAG_WRITE_COVERAGE, FLAG_TIMING = 1, 2
 FLAG_BGRA = 8  # colour images in B, G, R, A byte order (src/renderer/presenter.rs:472-478 on X11)
 FLAG_COMPAT_REFERENCE_INDEXING = 4  # draw list as the reference binary records it (src/renderer/drawer.rs:313-347)
 E_INVALID, E_DEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4
+MAX_DIM = 8192  # SXE_MAX_DIM: width and height limit of a frame
 
 EXPORTS = [
     "sxe_default_config", "sxe_create", "sxe_destroy", "sxe_last_error", "sxe_version", "sxe_set_textures",

@@ -428,6 +428,25 @@ def test_frame_with_more_than_8192_tiles_and_crowds_of_large_triangles(orc):
     assert_frames_equal(got, ref, what="8448 tiles")
 
 
+def test_the_largest_frame(orc):
+    """8192 x 8192, the stated limit: 65 536 tiles, pixel addresses up to 2^26, and one pixel more
+    either way is refused."""
+    s = scenes.sphere_field_scene(60, 12, 8.0, (-20.0, -1.0), api.MAX_DIM, api.MAX_DIM, n_textures=2, tex_size=32, name="largest-frame")
+    w, h = s.size
+    ref = orc.render(s, orc.to_model(s.transforms), *orc.camera(s.camera, w, h), w, h, threads=16)
+    with api.HipDrawer(w, h, n_images=1, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        d.draw(0)
+        d.sync()
+        assert d.stats()["tiles"] == 256 * 256
+        got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+    assert_frames_equal(got, ref, what="8192 x 8192")
+    for bad in ((api.MAX_DIM + 1, 64), (64, api.MAX_DIM + 1)):
+        with pytest.raises(api.SxeError):
+            api.HipDrawer(*bad)
+
+
 def test_frames_in_flight(orc):
     """Frames enqueued back to back without a host wait: every image must hold exactly its frame,
     also when the first frames overflow their work buffers and are drawn again after the fact
