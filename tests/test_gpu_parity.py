@@ -428,6 +428,31 @@ def test_frame_with_more_than_8192_tiles_and_crowds_of_large_triangles(orc):
     assert_frames_equal(got, ref, what="8448 tiles")
 
 
+def test_many_small_objects(orc):
+    """150 000 objects of one triangle each (the reference's loop has one draw per mesh,
+    src/renderer/drawer.rs:313-347): per-object arrays, work items and visibility flags far beyond
+    the benchmark's 10 000, every work item 255/256 empty; drawn twice with a rotation in between."""
+    from tests.util import random_soup, soup_scene
+    rng = np.random.default_rng(5)
+    n = 150000
+    tris = random_soup(rng, n, 640, 480, kinds=("small", "medium"))
+    s = soup_scene(tris, width=640, height=480, objects_split=[1] * n)
+    w, h = s.size
+    view, proj = orc.camera(s.camera, w, h)
+    with api.HipDrawer(w, h, coverage=True) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        for frame in range(2):
+            d.rotation_system(9, frame, 16.0)
+            d.draw(frame & 1)
+        d.sync()
+        assert d.stats()["objects"] == n
+        t = d.read_transforms()
+        got = {"color": d.read_color(1), "depth": d.read_depth(1), "prim": d.read_coverage(1)}
+    ref = orc.render(s, orc.to_model(t), view, proj, w, h, threads=16)
+    assert_frames_equal(got, ref, what="150 000 objects")
+
+
 def test_the_largest_frame(orc):
     """8192 x 8192, the stated limit: 65 536 tiles, pixel addresses up to 2^26, and one pixel more
     either way is refused."""
