@@ -34,7 +34,9 @@ constexpr int kEncPadded = (kEncEntries + 3) & ~3;
 
 __device__ inline uint32_t srgb_encode_lds(const uint32_t *enc, float x)
 {
-    const int bits = __float_as_int(x);
+    // (a NaN encodes as 0, like everything that is not above the first threshold: the larger of a
+    // NaN and 0 is 0; without this its sign bit would decide between 0 and 255)
+    const int bits = __float_as_int(fmaxf(x, 0.0f));
     const int idx = min(max((bits >> 16) - (kEncKeyLo - 1), 0), kEncEntries - 1);
     const uint32_t e = enc[idx];
     return (e >> 24) + (((uint32_t)bits & 0xFFFFu) >= (e & 0x1FFFFu) ? 1u : 0u);
@@ -77,6 +79,7 @@ static hipError_t upload_encode_table()
 static uint32_t srgb_encode_host(const uint32_t *enc, float x)
 {
     int bits;
+    if (!(x > 0.0f)) x = 0.0f;
     __builtin_memcpy(&bits, &x, 4);
     int idx = (bits >> 16) - (kEncKeyLo - 1);
     idx = idx < 0 ? 0 : (idx > kEncEntries - 1 ? kEncEntries - 1 : idx);

@@ -58,6 +58,41 @@ def test_triangle_soups(orc, seed):
     assert_frames_equal(got, ref, what="soup seed %d" % seed)
 
 
+@pytest.mark.parametrize("shading", [0, 1, 2, 3, "blend"])
+def test_vertices_and_matrices_that_are_not_finite(orc, shading):
+    """NaN, infinities, values near the largest float, denormals and -0 among the positions, texture
+    coordinates, colours and model matrices: such triangles are dropped or clipped the same way by
+    both implementations (every comparison written so that a NaN falls on the rejecting side), and
+    the rest of the frame is what it would be without them."""
+    from tests.util import random_soup, soup_scene
+    blend = shading == "blend"  # texture shading with a translucent texture: the ordered path
+    shading = 0 if blend else shading
+    rng = np.random.default_rng(35 if blend else 31 + shading)
+    n = 6000
+    tris = random_soup(rng, n, 256, 192)
+    bad = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3.0e38, 1e-40, -0.0], np.float32)
+    pick = rng.random((n, 3, 3)) < 0.02
+    tris[pick] = rng.choice(bad, size=int(pick.sum()))
+    uv = rng.uniform(0, 1, (n * 3, 2)).astype(np.float32)
+    pick = rng.random((n * 3, 2)) < 0.01
+    uv[pick] = rng.choice(bad, size=int(pick.sum()))
+    colors = rng.uniform(0, 1, (n * 3, 3)).astype(np.float32)
+    pick = rng.random((n * 3, 3)) < 0.01
+    colors[pick] = rng.choice(bad, size=int(pick.sum()))
+    textures = [scenes.translucent_texture(32, 9), scenes.checker_texture(16, 2)] if blend else None
+    s = soup_scene(tris, uvs=uv, colors=colors, width=256, height=192, objects_split=[100] * 60, textures=textures,
+                   tex_ids=(np.arange(60) % 2) if blend else None)
+    w, h = s.size
+    models = np.tile(IDENT, (len(s.objects), 1))
+    for o, k, v in ((3, 0, np.nan), (7, 5, np.inf), (11, 15, 0.0), (13, 12, 1e30), (17, 10, -np.inf)):
+        models[o, k] = v
+    ref = orc.render(s, models, IDENT, IDENT, w, h, shading=shading)
+    got = render_hip(s, models=models, view=IDENT, proj=IDENT, shading=shading)
+    assert (ref["prim"] != 0xFFFFFFFF).mean() > 0.5
+    # (a colour may be NaN where a NaN attribute was interpolated: compared as bits like everything else)
+    assert_frames_equal(got, ref, what="non-finite input")
+
+
 def test_fan_triangles_that_overlap_by_a_sliver(orc):
     """A triangle cut by the near and the far plane: the corners of its fan are snapped to the grid
     one by one, and at pixel (33, 51) of this frame two of the fan's triangles both cover the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: many random scenes, HIP frame against the oracle's, bit for bit (colour, depth,
-primitive id).  Triangle soups of every awkward kind at odd frame sizes, random shading mode (the lit extension under random lights among them),
+primitive id).  Triangle soups of every awkward kind at odd frame sizes (one in twelve with NaN, infinities and other wild values in it), random shading mode (the lit extension under random lights among them),
 random scissor band, several objects and textures, some objects not rendered, the draw list of the reference
 binary (SXE_FLAG_COMPAT_REFERENCE_INDEXING) and the BGRA target order now and then, through either upload entry
 point; sphere fields under random cameras.
@@ -65,11 +65,24 @@ def one_case(seed, case, verbose):
         for k, t in enumerate(texs):
             if not (translucent and k < 2):
                 t[..., 3] = 255
-        s = soup_scene(tris, uvs=rng.uniform(-0.5, 1.5, (3 * n, 2)), colors=rng.uniform(0, 1, (3 * n, 3)), textures=texs, width=w,
+        uvs, colors = rng.uniform(-0.5, 1.5, (3 * n, 2)).astype(np.float32), rng.uniform(0, 1, (3 * n, 3)).astype(np.float32)
+        # one soup in twelve has values that are not finite, near the largest float, denormal or -0
+        # among its positions, texture coordinates, colours and matrices (a generator of its own, so
+        # that the other cases of a seed stay what they were)
+        rng2 = np.random.default_rng(seed ^ 0x5EED)
+        wild = rng2.random() < 1.0 / 12.0
+        if wild:
+            bad = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3.0e38, 1e-40, -0.0], np.float32)
+            for arr, p in ((tris, 0.02), (uvs, 0.01), (colors, 0.01)):
+                pick = rng2.random(arr.shape) < p
+                arr[pick] = rng2.choice(bad, size=int(pick.sum()))
+        s = soup_scene(tris, uvs=uvs, colors=colors, textures=texs, width=w,
                        height=h, objects_split=split, tex_ids=rng.integers(0, 3, len(split)))
         models = np.tile(IDENT, (len(s.objects), 1))
+        if wild and rng2.random() < 0.5:
+            models[int(rng2.integers(0, len(models))), int(rng2.integers(0, 16))] = rng2.choice(bad)
         view = proj = IDENT
-        desc = "soup %d tris %dx%d %d objects%s" % (n, w, h, len(split), " translucent" if translucent else "")
+        desc = "soup %d tris %dx%d %d objects%s%s" % (n, w, h, len(split), " translucent" if translucent else "", " wild" if wild else "")
     scissor = None
     if rng.random() < 0.4:
         a, b = sorted(rng.integers(0, h + 1, 2).tolist())
