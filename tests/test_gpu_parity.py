@@ -93,6 +93,41 @@ def test_vertices_and_matrices_that_are_not_finite(orc, shading):
     assert_frames_equal(got, ref, what="non-finite input")
 
 
+def test_camera_and_transforms_that_are_not_finite(orc):
+    """A camera or an object pose with NaN or infinite components (update_camera and
+    update_transforms take whatever the ECS holds): the affected objects draw nothing or the same
+    pixels as in the oracle, the others are untouched, and the rotation system keeps going."""
+    s = scenes.config_scene(2, scale=0.2)
+    w, h = s.size
+    for k, (field, idx, value) in enumerate([("position", 0, np.nan), ("rotation", 1, np.inf), ("scale", 2, -np.inf), (None, 0, 0)]):
+        cam = s.camera.copy()
+        if field:
+            cam[field][0][idx] = value
+        t = s.transforms.copy()
+        t["position"][1][0] = np.nan
+        t["scale"][2][1] = np.inf
+        t["rotation"][3][2] = np.nan
+        t["scale"][4][:] = 0.0
+        with api.HipDrawer(w, h, coverage=True) as d:
+            d.update_scene(s)
+            d.update_transforms(t)
+            d.update_camera(cam)
+            d.rotation_system(5, k, 16.0)
+            d.draw(0)
+            d.sync()
+            t_after = d.read_transforms()
+            got = {"color": d.read_color(0), "depth": d.read_depth(0), "prim": d.read_coverage(0)}
+        t_ref = t.copy()
+        orc.rotation_system(t_ref, 5, k, 16.0)
+        # (bit for bit, except that a NaN may carry another sign or payload on the other processor)
+        fa, fb = t_after.view(np.float32), t_ref.view(np.float32)
+        assert ((fa.view(np.uint32) == fb.view(np.uint32)) | (np.isnan(fa) & np.isnan(fb))).all()
+        ref = orc.render(s, orc.to_model(t_ref), *orc.camera(cam, w, h), w, h)
+        assert_frames_equal(got, ref, what="non-finite %s" % (field or "poses only"))
+        if not field:
+            assert (ref["prim"] != 0xFFFFFFFF).any()
+
+
 def test_fan_triangles_that_overlap_by_a_sliver(orc):
     """A triangle cut by the near and the far plane: the corners of its fan are snapped to the grid
     one by one, and at pixel (33, 51) of this frame two of the fan's triangles both cover the
