@@ -676,6 +676,39 @@ def test_clipping_that_appears_after_quiet_frames(orc):
     assert_frames_equal(got_far, ref_far, what="cube back in front")
 
 
+def test_contexts_give_back_what_they_took():
+    """Device memory after a hundred contexts have been created, used (uploads, frames whose work
+    buffers grow, a view set, the allocation-free draw, readbacks) and destroyed is what it was
+    after the first one."""
+    import torch
+    s = scenes.config_scene(2, scale=0.25)
+    w, h = s.size
+    cams = scenes.orbit_cameras(3, 5)
+
+    def once():
+        with api.HipDrawer(w, h, n_images=3, coverage=True, timing=True) as d:
+            d.update_scene(s)
+            d.update_camera(s.camera)
+            for i in range(4):
+                d.rotation_system(1, i, 16.0)
+                d.draw(i % 3)
+            d.sync()
+            d.draw_views(cams, 0)
+            d.sync()
+            d.draw_noalloc(1)
+            d.read_color(1)
+            d.map_color(0)
+
+    once()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(100):
+        once()
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_before - free_after < (8 << 20), "device memory shrank by %d bytes over 100 contexts" % (free_before - free_after)
+
+
 def test_mapped_frame_equals_the_copied_one():
     s = scenes.cube_scene(160, 120)
     with api.HipDrawer(160, 120, n_images=2) as d:
