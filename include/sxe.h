@@ -13,6 +13,12 @@
  *
  * Errors: every function returns 0 or a negative SXE_E_* code and never aborts the process
  * (the reference panics instead: src/renderer/drawer.rs:453, src/renderer/types.rs:51).
+ *
+ * Values that are not finite (NaN, infinities) among vertex positions, attributes, matrices, poses
+ * or the camera are no error: a triangle with a corner that cannot be projected is not drawn, one
+ * that reaches beyond the clip volume is clipped, a colour that is a NaN is stored as 0, and the
+ * rest of the frame is what it would be without them.  Index and texture numbers out of range are
+ * refused when the scene is uploaded (SXE_E_INVALID).
  */
 #ifndef SXE_H
 #define SXE_H
