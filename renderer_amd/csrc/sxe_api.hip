@@ -172,7 +172,7 @@ struct sxe_ctx {
     DevBuf<sxe_transform> transforms;
     bool have_transforms = false;
     DevBuf<uint8_t> texels;    // the textures as they were given, back to back (source of the footprint tables)
-    DevBuf<uint4> footprints;  // (width + 1) x (height + 1) bilinear footprints per texture, back to back
+    DevBuf<uint2> footprints;  // (width + 2) x (height + 1) cells per texture, back to back (one spare at the end: a footprint is two cells)
     DevBuf<TexDev> textab;
     Mat4 view, proj, pv;
     LightDev light; // of SXE_SHADE_LIT
@@ -1168,7 +1168,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((e = c->counters.reserve(1)) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((k.flags & kDebugTileTimes) && (e = c->tile_times.reserve(8 * nt)) != hipSuccess) return bail("hipMalloc(tile times)", e);
     if ((e = c->texels.reserve(16)) != hipSuccess) return bail("hipMalloc(texels)", e);
-    if ((e = c->footprints.reserve(1)) != hipSuccess) return bail("hipMalloc(footprints)", e);
+    if ((e = c->footprints.reserve(2)) != hipSuccess) return bail("hipMalloc(footprints)", e);
     if ((e = c->textab.reserve(1)) != hipSuccess) return bail("hipMalloc(texture table)", e);
     *out = c;
     return SXE_OK;
@@ -1231,16 +1231,16 @@ int sxe_set_textures(sxe_ctx *c, const sxe_texture_desc *textures, uint32_t n)
         tab[t].height = d.height;
         tab[t].flags = translucent ? kTexTranslucent : 0u;
         total += px;
-        entries += ((size_t)d.width + 1) * ((size_t)d.height + 1);
+        entries += ((size_t)d.width + 2) * ((size_t)d.height + 1);
         if (entries > 0xFFFFFFF0ull) return fail(c, SXE_E_CAPACITY, "texture pool exceeds 2^32 texels");
     }
     rc = sxe_sync(c); // frames in flight still sample the old table
     if (rc) return rc;
     SXE_HIP(c, c->texels.reserve(std::max<size_t>(total * 4, 16)));
-    SXE_HIP(c, c->footprints.reserve(std::max<size_t>(entries, 1)));
+    SXE_HIP(c, c->footprints.reserve(entries + 2));
     SXE_HIP(c, c->textab.reserve(std::max<size_t>(n, 1)));
-    // The tile kernels sample tables of ready-made bilinear footprints (16 bytes per texel), built
-    // here on the device from the texels as given.
+    // The tile kernels sample tables of 8-byte cells (a texel and the one below it; two neighbouring
+    // cells are a bilinear footprint), built here on the device from the texels as given.
     for (uint32_t t = 0; t < n; ++t) {
         uint8_t *texels = c->texels.p + 4 * texel_at[t];
         SXE_HIP(c, hipMemcpyAsync(texels, textures[t].rgba, 4 * (size_t)tab[t].width * tab[t].height, hipMemcpyHostToDevice, c->stream));

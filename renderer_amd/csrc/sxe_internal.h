@@ -70,7 +70,7 @@ struct VBlockDesc { // work item of the vertex kernel: up to 1024 consecutive ve
 };
 
 struct TexDev {
-    uint32_t offset; // first entry of the texture's table in the pooled footprint tables
+    uint32_t offset; // first cell of the texture's table in the pooled tables
     uint32_t width, height;
     uint32_t flags;  // kTexTranslucent
 };
@@ -296,7 +296,7 @@ struct RasterArgs {
     size_t image_stride;        // pixels from one view's image to the next (views render into consecutive images)
     const FrameCounters *counters;
     FrameCounters *host_counters; // host-visible copy of the counters, written by the first workgroup (may be null)
-    const uint4 *footprints; // the textures as tables of bilinear footprints (TexDev::offset indexes it)
+    const uint2 *footprints; // the textures as tables of cells, two of which make a bilinear footprint (TexDev::offset indexes it)
     const TexDev *textures;
     uint32_t n_textures;
     uint8_t *out_color;   // RGBA8, row-major, full frame
@@ -327,6 +327,6 @@ hipError_t launch_clip(const SetupArgs &a, hipStream_t s);
 hipError_t launch_finish(const FinishArgs &a, hipStream_t s);
 hipError_t launch_raster_shade(const RasterArgs &a, hipStream_t s);
 hipError_t launch_raster_blend(const RasterArgs &a, hipStream_t s);
-hipError_t launch_texture_footprints(const uint8_t *texels, uint32_t width, uint32_t height, uint4 *footprints, hipStream_t s);
+hipError_t launch_texture_footprints(const uint8_t *texels, uint32_t width, uint32_t height, uint2 *cells, hipStream_t s);
 
 } // namespace sxe
