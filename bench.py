@@ -354,6 +354,10 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_all.get(dom),
                     "traffic_fetch_factor": traffic_all.get("fetch_factor"),
+                    # the bytes the kernel really moves at the L2's memory side (counters) over its
+                    # duration: how close the memory system is to its limit whatever the byte model says
+                    "traffic_GBps": (traffic_all.get(dom) / (stage_ms[dom] * 1e-3) / 1e9) if traffic_all.get(dom) and stage_ms[dom] > 0 else None,
+                    "traffic_frac": (traffic_all.get(dom) / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic_all.get(dom) and stage_ms[dom] > 0 else None,
                     # (false: profiles/pmc_*.json were collected on exactly these kernel sources)
                     "counters_stale": counters_stale, "counters_source_hash": traffic_all.get("source_hash"),
                     "source_hash": built_from,
