@@ -168,10 +168,10 @@ const char *sxe_version(void);
  * path that depth-tests and blends every fragment in submission order (BlendState::ALPHA,
  * src/renderer/drawer.rs:660-663): exact and much slower (a 32x32 tile that holds more than 4096
  * such triangles is sorted and blended in consecutive stretches of the submission order).
- * On the device a texture is kept as a table of its (width + 1) x (height + 1) bilinear footprints
- * (the four texels of every possible sample, clamp to edge applied; 16 bytes each) next to the
- * texels as given: about 20 bytes of device memory per texel; all tables together hold fewer than
- * 2^32 entries (SXE_E_CAPACITY). */
+ * On the device a texture is kept as a table of (width + 2) x (height + 1) cells of 8 bytes (a texel
+ * and the one below it, clamp to edge applied; two neighbouring cells are the four texels of a
+ * sample) next to the texels as given: about 12 bytes of device memory per texel; all tables
+ * together hold fewer than 2^32 cells (SXE_E_CAPACITY). */
 int sxe_set_textures(sxe_ctx *ctx, const sxe_texture_desc *textures, uint32_t n);
 /* One mesh per drawable, drawn once, as the reference stores them (src/renderer/drawer.rs:173-193). */
 int sxe_update_drawables(sxe_ctx *ctx, const sxe_drawable *drawables, uint32_t n);
