@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-depth-variant", action="store_true",
+                    help="leave out the second measurement with the depth images not kept (kernel traces of the headline alone)")
     ap.add_argument("--prewarm-frames", type=int, default=512,
                     help="untimed steps before the warm-up steps, so that the GPU's clocks have ramped up (0: none)")
     ap.add_argument("--check", action="store_true", help="compare the last frame with the oracle (slow)")
@@ -430,6 +432,30 @@ def main():
             result["check"] = {"color_equal": bool(np.array_equal(ref["color"], got)),
                                "depth_equal": bool(np.array_equal(ref["depth"][y0:y1].view(np.uint32), depth[y0:y1].view(np.uint32)))}
     drawer.close()
+    if world == 1 and not sortfirst and not args.no_depth_variant:
+        # The same frames with the depth images not kept, which is what the reference's pass does with its
+        # depth attachment (AttachmentStoreOp::DontCare, src/renderer/drawer.rs:544-547).  A second key, not
+        # the headline: the headline keeps the depth images, which the parity tests read.
+        d3 = api.HipDrawer(width, height, device=local_rank, n_images=2, discard_depth=True)
+        d3.update_scene(scene)
+        d3.update_camera(scene.camera)
+        dd_steps = max(200, args.steps)
+        for i in range(256):
+            d3.rotation_system(SEED, i, DELTA_MS)
+            d3.draw(i & 1)
+        d3.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(dd_steps):
+            d3.rotation_system(SEED, 256 + i, DELTA_MS)
+            d3.draw(i & 1)
+        d3.sync()
+        torch.cuda.synchronize()
+        dd_elapsed = time.perf_counter() - t0
+        d3.close()
+        result["depth_not_kept"] = {"value": n_prims * dd_steps / dd_elapsed, "unit": "triangles/s", "steps": dd_steps,
+                                    "ms_per_step": 1e3 * dd_elapsed / dd_steps,
+                                    "what": "SXE_FLAG_DISCARD_DEPTH: the reference's store op for its depth attachment"}
     if sortfirst and world > 1:
         # The other split as a second key: every rank draws whole frames of its own (frames r, r + N,
         # ...), no exchange, weak scaling.  After the headline measurement, on a context of its own.

@@ -20,6 +20,7 @@ pub const SXE_FLAG_TIMING: u32 = 2;
 pub const SXE_FLAG_COMPAT_REFERENCE_INDEXING: u32 = 4;
 /// Colour images in B, G, R, A byte order (the Bgra8Srgb surface format of src/renderer/presenter.rs:472-478).
 pub const SXE_FLAG_BGRA: u32 = 8;
+pub const SXE_FLAG_DISCARD_DEPTH: u32 = 16;
 
 #[repr(C)]
 pub struct sxe_ctx {

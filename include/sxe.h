@@ -65,6 +65,13 @@ extern "C" {
  * format its surface offers (src/renderer/presenter.rs:472-478), which on X11 is Bgra8Srgb; the
  * default here is R, G, B, A (its fallback, Rgba8Srgb).  Same values, other byte order. */
 #define SXE_FLAG_BGRA 8u
+/* Do not keep the depth images.  The reference's depth attachment is cleared when the pass begins
+ * and its contents are not stored when it ends (AttachmentStoreOp::DontCare,
+ * src/renderer/drawer.rs:544-547): depth exists for the test inside the frame only.  By default the
+ * library stores every frame's depth image for sxe_read_depth (what the parity tests compare); with
+ * this flag the depth test is the same, nothing is written, the images are not allocated and
+ * sxe_read_depth returns SXE_E_STATE. */
+#define SXE_FLAG_DISCARD_DEPTH 16u
 
 #define SXE_MAX_DIM 8192u          /* width and height limit (8K frames fit) */
 #define SXE_MAX_PRIMS (1u << 29)   /* triangles per frame */

@@ -23,6 +23,7 @@ OBJECT = np.dtype([("mesh", "<u4"), ("texture", "<i4"), ("rendered", "<u4")])
 SHADE_TEXTURE, SHADE_VERTEX_COLOR, SHADE_COLOR_TIMES_TEXTURE = 0, 1, 2
 SHADE_LIT = 3  # flat Blinn-Phong over the texture: an extension, the reference's shaders have no lighting
 FLAG_WRITE_COVERAGE, FLAG_TIMING = 1, 2
+FLAG_DISCARD_DEPTH = 16  # the depth images are not kept (AttachmentStoreOp::DontCare, src/renderer/drawer.rs:544-547)
 FLAG_BGRA = 8  # colour images in B, G, R, A byte order (src/renderer/presenter.rs:472-478 on X11)
 FLAG_COMPAT_REFERENCE_INDEXING = 4  # draw list as the reference binary records it (src/renderer/drawer.rs:313-347)
 E_INVALID, E_DEVICE, E_CAPACITY, E_STATE = -1, -2, -3, -4
@@ -244,7 +245,7 @@ class HipDrawer:
 
     def __init__(self, width, height, device=0, n_images=2, scissor=None, shading=SHADE_TEXTURE,
                  coverage=False, timing=False, clear=None, fov_deg=None, z_near=None, z_far=None, debug_flags=0,
-                 reference_indexing=False, bgra=False):
+                 reference_indexing=False, bgra=False, discard_depth=False):
         self._L = lib()
         self._ctx = C.c_void_p()
         cfg = Config()
@@ -257,7 +258,8 @@ class HipDrawer:
                 raise SxeError(E_INVALID, "empty scissor")
         cfg.shading = shading
         cfg.flags = ((FLAG_WRITE_COVERAGE if coverage else 0) | (FLAG_TIMING if timing else 0) | debug_flags |
-                     (FLAG_COMPAT_REFERENCE_INDEXING if reference_indexing else 0) | (FLAG_BGRA if bgra else 0))
+                     (FLAG_COMPAT_REFERENCE_INDEXING if reference_indexing else 0) | (FLAG_BGRA if bgra else 0) |
+                     (FLAG_DISCARD_DEPTH if discard_depth else 0))
         if debug_flags:
             # development switches (tools/ only): the library refuses them without this
             os.environ.setdefault("SXE_DEVELOPMENT", "1")

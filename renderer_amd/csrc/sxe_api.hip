@@ -1040,7 +1040,9 @@ int read_image_plane(sxe_ctx *c, uint32_t image_index, void *dst, size_t size_by
     rc = sxe_sync(c);
     if (rc) return rc;
     const void *src = plane == 0 ? (const void *)img.color : plane == 1 ? (const void *)img.depth : (const void *)img.prim;
-    if (!src) return fail(c, SXE_E_STATE, "coverage was not requested (SXE_FLAG_WRITE_COVERAGE)");
+    if (!src)
+        return fail(c, SXE_E_STATE, plane == 1 ? "the depth images are not kept (SXE_FLAG_DISCARD_DEPTH)"
+                                               : "coverage was not requested (SXE_FLAG_WRITE_COVERAGE)");
     // rows outside the scissor were never written: report them as cleared
     SXE_HIP(c, hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
     return SXE_OK;
@@ -1094,7 +1096,7 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     if ((k.flags & kDebugMask) && !(getenv("SXE_DEVELOPMENT") && getenv("SXE_DEVELOPMENT")[0] == '1'))
         return fail(nullptr, SXE_E_INVALID, "flags 0x%x: bits 26-31 are development switches (set SXE_DEVELOPMENT=1 to use them)",
                     k.flags & kDebugMask);
-    constexpr uint32_t kKnownFlags = SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | SXE_FLAG_COMPAT_REFERENCE_INDEXING | SXE_FLAG_BGRA | kDebugMask;
+    constexpr uint32_t kKnownFlags = SXE_FLAG_WRITE_COVERAGE | SXE_FLAG_TIMING | SXE_FLAG_COMPAT_REFERENCE_INDEXING | SXE_FLAG_BGRA | SXE_FLAG_DISCARD_DEPTH | kDebugMask;
     if (k.flags & ~kKnownFlags) return fail(nullptr, SXE_E_INVALID, "unknown flag bits 0x%x", k.flags & ~kKnownFlags);
     if (k.n_images == 0) k.n_images = 1;
     if (k.n_images > 65536) return fail(nullptr, SXE_E_CAPACITY, "at most 65536 images");
@@ -1150,16 +1152,17 @@ int sxe_create(const sxe_config *cfg, sxe_ctx **out)
     const size_t px = (size_t)k.width * k.height;
     c->images.resize(k.n_images);
     if ((e = c->color_pool.reserve(px * 4 * k.n_images)) != hipSuccess) return bail("hipMalloc(color)", e);
-    if ((e = c->depth_pool.reserve(px * k.n_images)) != hipSuccess) return bail("hipMalloc(depth)", e);
+    const bool keep_depth = !(k.flags & SXE_FLAG_DISCARD_DEPTH);
+    if (keep_depth && (e = c->depth_pool.reserve(px * k.n_images)) != hipSuccess) return bail("hipMalloc(depth)", e);
     if (k.flags & SXE_FLAG_WRITE_COVERAGE)
         if ((e = c->prim_pool.reserve(px * k.n_images)) != hipSuccess) return bail("hipMalloc(coverage)", e);
     // rows outside the scissor are never written by a frame: start them cleared
     if ((e = hipMemset(c->color_pool.p, 0, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(c->depth_pool.p, 0, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
+    if (keep_depth && (e = hipMemset(c->depth_pool.p, 0, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
     if (c->prim_pool.p && (e = hipMemset(c->prim_pool.p, 0xFF, px * 4 * k.n_images)) != hipSuccess) return bail("hipMemset", e);
     for (uint32_t i = 0; i < k.n_images; ++i) {
         c->images[i].color = c->color_pool.p + px * 4 * i;
-        c->images[i].depth = c->depth_pool.p + px * i;
+        c->images[i].depth = keep_depth ? c->depth_pool.p + px * i : nullptr;
         c->images[i].prim = c->prim_pool.p ? c->prim_pool.p + px * i : nullptr;
     }
     const size_t nt = std::max<uint32_t>(c->g.n_tiles, 1);

@@ -300,7 +300,7 @@ struct RasterArgs {
     const TexDev *textures;
     uint32_t n_textures;
     uint8_t *out_color;   // RGBA8, row-major, full frame
-    float *out_depth;
+    float *out_depth;     // may be null (SXE_FLAG_DISCARD_DEPTH)
     uint32_t *out_prim;   // may be null
     unsigned long long *tile_times; // development: 8 clock values per tile (phase stamps), or null
     uint32_t clear_code;  // encoded clear colour, little-endian RGBA

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
     if (a.blend_scene && !overflow && ((uint32_t)__builtin_amdgcn_readfirstlane((int)launch2.w) & kTileBlend)) return;
     // every view renders into its own image, one behind the other
     a.out_color += 4 * a.image_stride * view;
-    a.out_depth += a.image_stride * view;
+    if (a.out_depth) a.out_depth += a.image_stride * view; // (null: the depth images are not kept)
     if (COVERAGE) a.out_prim += a.image_stride * view;
 #define SXE_STAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_STAMP(0);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             if (i > cx1 || j < cy0 || j > cy1) continue;
             const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
             reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(a.clear_code, a.bgra);
-            a.out_depth[p] = 1.0f;
+            if (a.out_depth) a.out_depth[p] = 1.0f;
             if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
         }
         return;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
         const bool covered = (uint32_t)(v >> 32) != 0x3F800000u; // (a fragment's depth is below 1)
         const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
         reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(covered ? (uint32_t)v : a.clear_code, a.bgra);
-        a.out_depth[p] = __uint_as_float((uint32_t)(v >> 32));
+        if (a.out_depth) a.out_depth[p] = __uint_as_float((uint32_t)(v >> 32));
         if (COVERAGE && !covered) a.out_prim[p] = 0xFFFFFFFFu;
     }
     SXE_STAMP(7);
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
 #define SXE_BSTAMP(i) do { if (a.tile_times && tid == 0) a.tile_times[8 * tile + (i)] = wall_clock64(); } while (0)
     SXE_BSTAMP(0);
     a.out_color += 4 * a.image_stride * view;
-    a.out_depth += a.image_stride * view;
+    if (a.out_depth) a.out_depth += a.image_stride * view; // (null: the depth images are not kept)
     if (COVERAGE) a.out_prim += a.image_stride * view;
     for (int i = tid; i < kEncPadded; i += kBlendThreads) s_enc[i] = reinterpret_cast<const uint32_t *>(g_srgb_encode)[i];
     if (tid < 256) {
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
     if (ox <= cx1 && oy >= cy0 && oy <= cy1) {
         const size_t p = (size_t)(__umul24((uint32_t)oy, a.g.width) + (uint32_t)ox);
         reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(s_out[tid], a.bgra);
-        a.out_depth[p] = __uint_as_float(s_out[kTile * kTile + tid]);
+        if (a.out_depth) a.out_depth[p] = __uint_as_float(s_out[kTile * kTile + tid]);
         if (COVERAGE) a.out_prim[p] = s_out[2 * kTile * kTile + tid];
     }
     SXE_BSTAMP(3);

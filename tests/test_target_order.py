@@ -43,3 +43,26 @@ def test_hip_bgra_equals_oracle(orc):
             assert np.array_equal(d.read_color(0), want["color"]), s.name
             assert np.array_equal(d.read_depth(0).view(np.uint32), want["depth"].view(np.uint32))
             assert np.array_equal(d.map_color(0), want["color"])
+
+
+@pytest.mark.gpu
+def test_depth_images_that_are_not_kept(orc):
+    """SXE_FLAG_DISCARD_DEPTH, the reference's AttachmentStoreOp::DontCare for the depth attachment
+    (src/renderer/drawer.rs:544-547): colour and coverage are what they are with the depth images
+    kept (the test inside the frame is the same), on the opaque and on the ordered path and for the
+    allocation-free draw; reading the depth back is refused."""
+    for s in _scenes():
+        w, h = s.size
+        want = _orc(orc, s, 0)
+        with api.HipDrawer(w, h, coverage=True, discard_depth=True) as d:
+            d.update_scene(s)
+            d.update_camera(s.camera)
+            d.draw(0)
+            d.sync()
+            assert np.array_equal(d.read_color(0), want["color"]), s.name
+            assert np.array_equal(d.read_coverage(0), want["prim"])
+            with pytest.raises(api.SxeError) as e:
+                d.read_depth(0)
+            assert e.value.code == api.E_STATE
+            d.draw_noalloc(1)
+            assert np.array_equal(d.read_color(1), want["color"])

@@ -17,7 +17,7 @@ cp profiles/pmc_mem.json $O/pmc_mem.json
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 cd $R && timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 > $O/bench.json 2> $O/bench.err || exit 1
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/trace.json 2> $O/trace.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-depth-variant > $O/trace.json 2> $O/trace.err || exit 1
 cd $R
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 cat $O/bench.json
