@@ -204,6 +204,16 @@ __device__ inline uint32_t target_order(uint32_t rgba, uint32_t bgra)
     return bgra ? __builtin_amdgcn_perm(rgba, rgba, 0x03000102u) : rgba;
 }
 
+// A finished pixel goes to its images with the streaming hint: nothing on this GPU reads the images
+// before the frame is complete, and as ordinary dirty lines 66 MB of them per 4K frame sit in the
+// L2 while the records and texture tables of this frame, and the geometry kernel of the next one,
+// want it (2 % of the frame).
+__device__ inline void store_pixel(const RasterArgs &a, size_t p, uint32_t color, float depth)
+{
+    __builtin_nontemporal_store(color, reinterpret_cast<uint32_t *>(a.out_color) + p);
+    if (a.out_depth) __builtin_nontemporal_store(depth, a.out_depth + p);
+}
+
 __device__ inline float clamp_depth(float z)
 {
     if (!(z > 0.0f)) z = 0.0f;
@@ -594,8 +604,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
             const int32_t i = tpx + (tid & (kTile - 1)), j = tpy + (tid / kTile) + k * (kRasterThreads / kTile);
             if (i > cx1 || j < cy0 || j > cy1) continue;
             const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
-            reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(a.clear_code, a.bgra);
-            if (a.out_depth) a.out_depth[p] = 1.0f;
+            store_pixel(a, p, target_order(a.clear_code, a.bgra), 1.0f);
             if (COVERAGE) a.out_prim[p] = 0xFFFFFFFFu;
         }
         return;
@@ -809,8 +818,7 @@ __global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(
         const unsigned long long v = vis[tid + k * kRasterThreads];
         const bool covered = (uint32_t)(v >> 32) != 0x3F800000u; // (a fragment's depth is below 1)
         const size_t p = (size_t)(__umul24((uint32_t)j, a.g.width) + (uint32_t)i); // (frames are at most 8192 wide and high)
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(covered ? (uint32_t)v : a.clear_code, a.bgra);
-        if (a.out_depth) a.out_depth[p] = __uint_as_float((uint32_t)(v >> 32));
+        store_pixel(a, p, target_order(covered ? (uint32_t)v : a.clear_code, a.bgra), __uint_as_float((uint32_t)(v >> 32)));
         if (COVERAGE && !covered) a.out_prim[p] = 0xFFFFFFFFu;
     }
     SXE_STAMP(7);
@@ -1223,8 +1231,7 @@ __global__ __launch_bounds__(kBlendThreads) void k_raster_blend(RasterArgs a)
     const int32_t ox = tpx + (tid & 31), oy = tpy + (tid >> 5);
     if (ox <= cx1 && oy >= cy0 && oy <= cy1) {
         const size_t p = (size_t)(__umul24((uint32_t)oy, a.g.width) + (uint32_t)ox);
-        reinterpret_cast<uint32_t *>(a.out_color)[p] = target_order(s_out[tid], a.bgra);
-        if (a.out_depth) a.out_depth[p] = __uint_as_float(s_out[kTile * kTile + tid]);
+        store_pixel(a, p, target_order(s_out[tid], a.bgra), __uint_as_float(s_out[kTile * kTile + tid]));
         if (COVERAGE) a.out_prim[p] = s_out[2 * kTile * kTile + tid];
     }
     SXE_BSTAMP(3);
