@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-depth-variant", action="store_true",
                     help="leave out the second measurement with the depth images not kept (kernel traces of the headline alone)")
-    ap.add_argument("--prewarm-frames", type=int, default=512,
+    ap.add_argument("--prewarm-frames", type=int, default=2048,
                     help="untimed steps before the warm-up steps, so that the GPU's clocks have ramped up (0: none)")
     ap.add_argument("--check", action="store_true", help="compare the last frame with the oracle (slow)")
     ap.add_argument("--bands", choices=["auto", "even"], default="auto",
