@@ -19,8 +19,10 @@ N > 1 (one process per GPU, launched by torch.distributed.run):
   frames     frame-parallel: rank r renders animation frames r, r+N, ...; every rank advances the
              replicated rotation state through all frames; no data-path collective.  One step = N
              frames.  Weak scaling.
-             (A sortfirst run measures this split as well, briefly, after the headline figure, and
-             reports it under the key "frame_parallel".)
+             (A sortfirst run measures this split as well, before the headline figure, and reports
+             it under the key "frame_parallel"; should the band exchange then fail or not finish
+             within --watchdog-seconds, that measurement is the line the run prints, with the
+             failure under the key "sortfirst".)
 
 Prints ONE JSON line on rank 0.
 """
@@ -121,6 +123,94 @@ def profile_file(name):
         return None
 
 
+def measure_frame_parallel(api, torch, dist, scene, local_rank, world, rank, steps, warmup, prewarm, stat_device):
+    """The frame-parallel split of N ranks: rank r draws animation frames r, r + N, ... (every rank
+    advances the replicated rotation state through all frames), no exchange.  One step = N frames.
+    Exactly `steps` steps between fences, the maximum over the ranks."""
+    width, height = scene.size
+    d2 = api.HipDrawer(width, height, device=local_rank, n_images=2)
+    d2.update_scene(scene)
+    d2.update_camera(scene.camera)
+    done = 0  # frames of the animation whose rotation update this rank has applied
+
+    def frame_step(i):
+        nonlocal done
+        target = i * world + rank
+        if done <= target:
+            d2.rotation_system(SEED, done, DELTA_MS, n_frames=target - done + 1)
+            done = target + 1
+        d2.update_camera(scene.camera)
+        d2.draw(i & 1)
+
+    def fence():
+        d2.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    for i in range(prewarm + warmup):
+        frame_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        frame_step(prewarm + warmup + i)
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=stat_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    d2.close()
+    elapsed = float(t.item())
+    return {"value": scene.n_triangles * steps * world / elapsed, "unit": "triangles/s", "scaling": "weak",
+            "steps": steps, "warmup": warmup, "frames_per_step": world, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+            "frames_per_sec": steps * world / elapsed, "parallelism": "frame-parallel%d, no exchange" % world}
+
+
+def fallback_line(args, scene, world, fp, why):
+    """The line of a sort-first run whose band exchange did not come through: the frame-parallel
+    measurement taken before it, under the same contract, and what happened to the other."""
+    width, height = scene.size
+    return {"metric": "triangles_per_sec", "value": fp["value"], "unit": "triangles/s", "n_gpus": world,
+            "steps": fp["steps"], "warmup": fp["warmup"], "ms_per_step": fp["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32+i64", "data": "synthetic",
+            "frames_per_sec": fp["frames_per_sec"],
+            "config": {"workload": "config %d: %s, %d objects x 1024 triangles = %d triangles, %dx%d, per-frame device-side "
+                                   "rotation update" % (args.config, scene.name, len(scene.objects), scene.n_triangles, width, height),
+                       "parallelism": "frame-parallel%d" % world, "frames_per_step": world},
+            "roofline": None, "cpu_baseline": None,
+            "sortfirst": {"error": why, "note": "the sort-first measurement did not finish; this line is the frame-parallel "
+                                                "split of the same workload, measured before it"}}
+
+
+class Watchdog:
+    """Ends a multi-rank run whose exchange hangs: after `seconds` without finish(), rank 0 prints
+    the line it was given and every rank leaves (a rank stuck inside a collective cannot be
+    interrupted from Python, so the process ends from this thread)."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.line, self.rank, self.seconds = None, rank, seconds
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def start(self, line):
+        self.line = line
+        if self.seconds > 0:
+            self.thread.start()
+
+    def run(self):
+        if not self.done.wait(self.seconds):
+            self.leave("no result within %d s" % self.seconds)
+
+    def leave(self, why):
+        if self.rank == 0 and self.line is not None:
+            self.line["sortfirst"]["error"] = why
+            print(json.dumps(self.line), flush=True)
+        sys.stderr.write("[bench] rank %d leaves: sort-first measurement failed (%s)\n" % (self.rank, why))
+        sys.stderr.flush()
+        os._exit(0 if self.line is not None or self.rank != 0 else 3)
+
+    def finish(self):
+        self.done.set()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +229,9 @@ def main():
                     help="sortfirst: band heights evened out against the measured gather (auto) or equal")
     ap.add_argument("--pipeline", action="store_true",
                     help="with one GPU: go through the sort-first gather pipeline anyway (its band is the whole frame)")
+    ap.add_argument("--watchdog-seconds", type=int, default=240,
+                    help="N > 1, sort-first: time allowed for that measurement before the run ends with the "
+                         "frame-parallel line taken first (0: no limit)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +276,36 @@ def main():
         d.update_camera(scene.camera)
         return d
 
+    # N ranks, sort-first: the other split first (every rank draws whole frames of its own, no
+    # exchange, weak scaling).  It is reported beside the headline, and it is the line of a run
+    # whose band exchange fails or hangs: the exchange is the one part no single-GPU run exercises.
+    frame_parallel, watchdog = None, None
+    if sortfirst and world > 1:
+        frame_parallel = measure_frame_parallel(api, torch, dist, scene, local_rank, world, rank, args.steps, args.warmup,
+                                                min(max(0, args.prewarm_frames), 512), stat_device)
+        watchdog = Watchdog(args.watchdog_seconds, rank)
+        watchdog.start(fallback_line(args, scene, world, frame_parallel, "") if rank == 0 else None)
+    try:
+        run_headline(args, api, torch, dist, scenes, shard, scene, world, rank, local_rank, rehearsal, stat_device, sortfirst,
+                     scissor, make_drawer, frame_parallel)
+    except Exception as e:  # noqa: BLE001 (whatever the exchange raises, the frame-parallel line still goes out)
+        if watchdog is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        watchdog.leave("%s: %s" % (type(e).__name__, str(e)[:300]))
+    if watchdog is not None:
+        watchdog.finish()
+
+
+def run_headline(args, api, torch, dist, scenes, shard, scene, world, rank, local_rank, rehearsal, stat_device, sortfirst,
+                 scissor, make_drawer, frame_parallel):
+    width, height = scene.size
+    n_prims = scene.n_triangles
+    if os.environ.get("SXE_BENCH_TEST_FAIL") == "raise" and sortfirst and world > 1 and rank == world - 1:
+        raise RuntimeError("injected failure (test of the fallback line)")
+    if os.environ.get("SXE_BENCH_TEST_FAIL") == "hang" and sortfirst and world > 1 and rank == world - 1:
+        time.sleep(10 ** 6)
     drawer = make_drawer(scissor)
     weights, tuning, first_frame = None, None, 0
     if sortfirst and world > 1 and args.bands == "auto":
@@ -456,44 +579,9 @@ def main():
         result["depth_not_kept"] = {"value": n_prims * dd_steps / dd_elapsed, "unit": "triangles/s", "steps": dd_steps,
                                     "ms_per_step": 1e3 * dd_elapsed / dd_steps,
                                     "what": "SXE_FLAG_DISCARD_DEPTH: the reference's store op for its depth attachment"}
-    if sortfirst and world > 1:
-        # The other split as a second key: every rank draws whole frames of its own (frames r, r + N,
-        # ...), no exchange, weak scaling.  After the headline measurement, on a context of its own.
-        del pipe
-        fp_steps, fp_warmup = max(8, min(args.steps, 50)), 3
-        d2 = api.HipDrawer(width, height, device=local_rank, n_images=2)
-        d2.update_scene(scene)
-        d2.update_camera(scene.camera)
-        done = 0  # frames of the animation whose rotation update this rank has applied
-
-        def frame_step(i):
-            nonlocal done
-            target = i * world + rank
-            if done <= target:
-                d2.rotation_system(SEED, done, DELTA_MS, n_frames=target - done + 1)
-                done = target + 1
-            d2.draw(i & 1)
-
-        for i in range(fp_warmup):
-            frame_step(i)
-        d2.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for i in range(fp_steps):
-            frame_step(fp_warmup + i)
-        d2.sync()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=stat_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        d2.close()
-        if rank == 0:
-            fp_elapsed = float(t.item())
-            result["frame_parallel"] = {"value": n_prims * fp_steps * world / fp_elapsed, "unit": "triangles/s", "scaling": "weak",
-                                        "steps": fp_steps, "warmup": fp_warmup, "frames_per_step": world,
-                                        "ms_per_step": 1e3 * fp_elapsed / fp_steps,
-                                        "parallelism": "frame-parallel%d, no exchange" % world}
+    if frame_parallel is not None and rank == 0:
+        result["frame_parallel"] = frame_parallel  # (measured before the headline, on a context of its own)
+    pipe = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

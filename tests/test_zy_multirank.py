@@ -43,3 +43,25 @@ def test_sort_first_bench_with_ranks_sharing_one_gpu(world, config):
     # the frame-parallel split is measured as a second key
     fp = out["frame_parallel"]
     assert fp["scaling"] == "weak" and fp["frames_per_step"] == world and fp["value"] > 0
+    assert fp["steps"] == 6 and fp["warmup"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("failure", ["raise", "hang"])
+def test_a_band_exchange_that_fails_leaves_the_frame_parallel_line(failure):
+    """The exchange is the one part of an N-rank run that no single-GPU run exercises with its real
+    transport: when it raises, or does not come back, the run still ends, with status 0 and the
+    frame-parallel measurement (taken first, under the same contract) as its line."""
+    world = 2
+    env = dict(os.environ, SXE_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", SXE_BENCH_TEST_FAIL=failure)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+           "--config", "3", "--scale", "0.25", "--prewarm-frames", "8", "--watchdog-seconds", "25"]
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["steps"] == 6 and out["warmup"] == 2
+    assert out["value"] > 0 and out["config"]["parallelism"] == "frame-parallel2"
+    assert out["sortfirst"]["error"]
