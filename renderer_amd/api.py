@@ -476,3 +476,127 @@ class HipDrawer:
         s = FrameStats()
         self._check(self._L.sxe_get_stats(self._ctx, C.byref(s)))
         return s.as_dict()
+
+
+class FramesInFlight:
+    """One context per target image: the reference keeps a command buffer and a fence per swapchain
+    image and submits frame i + 1 while image i is still being rendered
+    (src/renderer/drawer.rs:412-456).  Here every image's context has its own HIP stream and work
+    buffers, so the frames of different images overlap on the GPU: the geometry kernels of one frame
+    fill the vector ALUs while the tile kernel of the frame before waits for memory.  What the
+    caller sees is the Drawer of one context: state calls go to every context, draw(image_index) to
+    the context of that image, and the rotation system's updates are applied by each context when it
+    next draws, as one span over the frames it did not draw (the replicated state of frame-parallel
+    ranks).  Every frame is the frame a single context draws, bit for bit."""
+
+    def __init__(self, width, height, n_images=2, **kw):
+        if n_images < 1:
+            raise SxeError(E_INVALID, "FramesInFlight needs at least one image")
+        self.width, self.height = width, height
+        self.contexts = []
+        try:
+            for _ in range(n_images):
+                self.contexts.append(HipDrawer(width, height, n_images=1, **kw))
+        except Exception:
+            self.close()
+            raise
+        self._waiting = [[] for _ in range(n_images)]  # rotation updates (seed, first frame, frames, delta) not applied yet
+
+    def close(self):
+        for d in self.contexts:
+            d.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _all(self, name, *a, **kw):
+        for d in self.contexts:
+            getattr(d, name)(*a, **kw)
+
+    def _context(self, image_index):
+        if not 0 <= image_index < len(self.contexts):
+            raise SxeError(E_INVALID, "image index %d of %d" % (image_index, len(self.contexts)))
+        return image_index
+
+    def _apply_waiting(self, k):
+        """Hand context k the updates it has missed: runs of consecutive frames as one span each."""
+        runs = []
+        for seed, first, n, delta in self._waiting[k]:
+            if runs and runs[-1][0] == seed and runs[-1][3] == delta and runs[-1][1] + runs[-1][2] == first:
+                runs[-1][2] += n
+            else:
+                runs.append([seed, first, n, delta])
+        self._waiting[k] = []
+        for seed, first, n, delta in runs:
+            self.contexts[k].rotation_system(seed, first, delta, n_frames=n)
+
+    # ---- scene and per-frame state: every context ----
+    def set_textures(self, textures):
+        self._all("set_textures", textures)
+
+    def set_light(self, **kw):
+        self._all("set_light", **kw)
+
+    def update_drawables(self, drawables):
+        self._forget_updates()
+        self._all("update_drawables", drawables)
+
+    def update_scene(self, scene, transforms=None):
+        self._forget_updates()
+        self._all("update_scene", scene, transforms)
+
+    def update_uniforms(self, models):
+        self._forget_updates()
+        self._all("update_uniforms", models)
+
+    def update_transforms(self, transforms):
+        self._forget_updates()
+        self._all("update_transforms", transforms)
+
+    def _forget_updates(self):
+        # (what replaces every transform makes the rotations still waiting for it void)
+        self._waiting = [[] for _ in self.contexts]
+
+    def update_camera(self, transform):
+        self._all("update_camera", transform)
+
+    def update_camera_matrices(self, view, proj):
+        self._all("update_camera_matrices", view, proj)
+
+    def rotation_system(self, seed, frame, delta_ms, n_frames=1):
+        for w in self._waiting:
+            w.append((seed, frame, n_frames, delta_ms))
+
+    # ---- frames ----
+    def draw(self, image_index=0):
+        k = self._context(image_index)
+        self._apply_waiting(k)
+        self.contexts[k].draw(0)
+
+    def sync(self):
+        self._all("sync")
+
+    def read_color(self, image_index=0):
+        return self.contexts[self._context(image_index)].read_color(0)
+
+    def read_depth(self, image_index=0):
+        return self.contexts[self._context(image_index)].read_depth(0)
+
+    def read_coverage(self, image_index=0):
+        return self.contexts[self._context(image_index)].read_coverage(0)
+
+    def read_transforms(self):
+        self._apply_waiting(0)
+        return self.contexts[0].read_transforms()
+
+    def set_timing_stride(self, every):
+        self._all("set_timing_stride", every)
+
+    def stats(self):
+        """Frame statistics of the first context, with the redraws of all of them."""
+        s = self.contexts[0].stats()
+        s["redraws"] = sum(d.stats()["redraws"] for d in self.contexts)
+        return s
