@@ -73,3 +73,38 @@ def test_overlapping_frames_with_updates_that_are_not_consecutive(orc):
                 assert_frames_equal(got, want, what="after update %d" % k)
     with pytest.raises(api.SxeError):
         api.FramesInFlight(w, h, n_images=2).draw(2)
+
+
+@pytest.mark.gpu
+def test_overlapping_frames_at_full_size(orc):
+    """Config 3 as the bench draws it (10.24 M triangles, 3840x2160): frames of 0.2 ms that do overlap
+    on the GPU.  The last frame of each image equals the frame a single context draws for that place
+    in the animation, and the very last one the oracle's."""
+    s = scenes.config_scene(3)
+    w, h = s.size
+    frames = 8
+    with api.FramesInFlight(w, h, n_images=2) as d:
+        d.update_scene(s)
+        d.update_camera(s.camera)
+        for f in range(frames):
+            d.rotation_system(3, f, 16.0)
+            d.draw(f & 1)
+        d.sync()
+        got = {img: (d.read_color(img), d.read_depth(img)) for img in (0, 1)}
+    with api.HipDrawer(w, h, n_images=2) as one:
+        one.update_scene(s)
+        one.update_camera(s.camera)
+        for f in range(frames):
+            one.rotation_system(3, f, 16.0)
+            one.draw(f & 1)
+            if f >= frames - 2:
+                one.sync()
+                color, depth = one.read_color(f & 1), one.read_depth(f & 1)
+                assert np.array_equal(color, got[f & 1][0]), "colour of frame %d" % f
+                assert np.array_equal(depth.view(np.uint32), got[f & 1][1].view(np.uint32)), "depth of frame %d" % f
+        t = one.read_transforms()
+    view, proj = orc.camera(s.camera, w, h)
+    want = orc.render(s, orc.to_model(t), view, proj, w, h, threads=16)
+    last = (frames - 1) & 1
+    assert np.array_equal(want["color"], got[last][0])
+    assert np.array_equal(want["depth"].view(np.uint32), got[last][1].view(np.uint32))
