@@ -482,8 +482,8 @@ class FramesInFlight:
     """One context per target image: the reference keeps a command buffer and a fence per swapchain
     image and submits frame i + 1 while image i is still being rendered
     (src/renderer/drawer.rs:412-456).  Here every image's context has its own HIP stream and work
-    buffers, so the frames of different images overlap on the GPU: the geometry kernels of one frame
-    fill the vector ALUs while the tile kernel of the frame before waits for memory.  What the
+    buffers, so the frames of different images may overlap on the GPU (config 3 gains 5 % in frame
+    rate that way; a frame dominated by its tile kernel gains nothing).  What the
     caller sees is the Drawer of one context: state calls go to every context, draw(image_index) to
     the context of that image, and the rotation system's updates are applied by each context when it
     next draws, as one span over the frames it did not draw (the replicated state of frame-parallel
