@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the raster/shade hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--mode sortfirst|frames] [--config 3|4]
+  python bench.py --gpus N --steps K --warmup W [--mode auto|sortfirst|frames] [--config 3|4]
 
 Workload (config 3 of BASELINE.json): 10,000 instances of a 1,024-triangle mesh = 10.24 M
 triangles, 3840x2160, with the per-frame ECS rotation update running on the device.  One step is
@@ -9,20 +9,23 @@ one pass of the hot path: rotation system -> camera -> draw of one frame, inputs
 --config 4 is the same scene at 7680x4320.
 
 N > 1 (one process per GPU, launched by torch.distributed.run):
-  sortfirst  (default) each frame is cut into N bands of whole tile rows; geometry is replicated;
-             the finished bands are gathered on rank 0 over RCCL (grouped send/receive, every band
-             at its own size) while the next frame is being drawn.  One step = 1 frame.  Strong
-             scaling: the metric BASELINE.json names.  Before the warm-up the ranks time the
-             drawing of equal bands and their gather on their own; when the gather is the slower
-             of the two (few ranks: each band is a large share of the frame over one link), rank 0,
-             which sends nothing, takes a taller band (--bands even: equal bands).
   frames     frame-parallel: rank r renders animation frames r, r+N, ...; every rank advances the
              replicated rotation state through all frames; no data-path collective.  One step = N
-             frames.  Weak scaling.
-             (A sortfirst run measures this split as well, before the headline figure, and reports
-             it under the key "frame_parallel"; should the band exchange then fail or not finish
-             within --watchdog-seconds, that measurement is the line the run prints, with the
-             failure under the key "sortfirst".)
+             frames.  Weak scaling: what a frame of 0.2 ms asks for when the goal is frames per second.
+  sortfirst  each frame is cut into N bands of whole tile rows; geometry is replicated; the finished
+             bands are gathered on rank 0 over RCCL (grouped send/receive, every band at its own
+             size) while the next frame is being drawn.  One step = 1 frame.  Strong scaling: what a
+             frame asks for when the goal is its latency (the 8K frame of config 4).  Before the
+             warm-up the ranks time the drawing of equal bands and their gather on their own; when
+             the gather is the slower of the two (few ranks: each band is a large share of the frame
+             over one link), rank 0, which sends nothing, takes a taller band (--bands even: equal
+             bands).
+  auto       (default) frames for config 3, sortfirst for config 4.
+  Either way the other split is measured too and reported under a key of its own ("sort_first" or
+  "frame_parallel").  The band exchange is the one part of an N-rank run that no single-GPU run
+  exercises with its real transport: whatever it raises, and a hang beyond --watchdog-seconds, ends
+  up under that key (or, when sort-first is the headline, makes the frame-parallel measurement taken
+  first the line of the run) instead of costing the run its line.
 
 Prints ONE JSON line on rank 0.
 """
@@ -190,8 +193,8 @@ class Watchdog:
         self.done = threading.Event()
         self.thread = threading.Thread(target=self.run, daemon=True)
 
-    def start(self, line):
-        self.line = line
+    def start(self, line, key="sortfirst"):
+        self.line, self.key = line, key
         if self.seconds > 0:
             self.thread.start()
 
@@ -201,7 +204,7 @@ class Watchdog:
 
     def leave(self, why):
         if self.rank == 0 and self.line is not None:
-            self.line["sortfirst"]["error"] = why
+            self.line.setdefault(self.key, {})["error"] = why
             print(json.dumps(self.line), flush=True)
         sys.stderr.write("[bench] rank %d leaves: sort-first measurement failed (%s)\n" % (self.rank, why))
         sys.stderr.flush()
@@ -216,7 +219,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["sortfirst", "frames"], default="sortfirst")
+    ap.add_argument("--mode", choices=["auto", "sortfirst", "frames"], default="auto")
     ap.add_argument("--config", type=int, default=3, choices=[3, 4])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -265,41 +268,72 @@ def main():
     scene = scenes.config_scene(args.config, scale=args.scale)
     width, height = scene.size
     n_prims = scene.n_triangles
-    sortfirst = (args.mode == "sortfirst" and world > 1) or (world == 1 and args.pipeline)
-    scissor = shard.band_rows(height, world, rank) if sortfirst else None
-    if sortfirst and scissor[1] <= scissor[0]:
+    mode = args.mode
+    if mode == "auto":
+        mode = "sortfirst" if args.config == 4 else "frames"
+    sortfirst = (mode == "sortfirst" and world > 1) or (world == 1 and args.pipeline)
+    band = shard.band_rows(height, world, rank)
+    if world > 1 and band[1] <= band[0] and (sortfirst or not args.no_depth_variant):
         sys.exit("rank %d has no tile row to render (%d ranks for %d rows)" % (rank, world, height))
 
-    def make_drawer(band):
-        d = api.HipDrawer(width, height, device=local_rank, n_images=2, scissor=band, timing=True)
+    def make_drawer(scissor):
+        d = api.HipDrawer(width, height, device=local_rank, n_images=2, scissor=scissor, timing=True)
         d.update_scene(scene)
         d.update_camera(scene.camera)
         return d
 
-    # N ranks, sort-first: the other split first (every rank draws whole frames of its own, no
-    # exchange, weak scaling).  It is reported beside the headline, and it is the line of a run
-    # whose band exchange fails or hangs: the exchange is the one part no single-GPU run exercises.
-    frame_parallel, watchdog = None, None
-    if sortfirst and world > 1:
+    def measure(sort_first):
+        return run_measurement(args, api, torch, dist, shard, scene, world, rank, local_rank, rehearsal, stat_device, sort_first,
+                               band if sort_first else None, make_drawer)
+
+    def guarded(watchdog, what):
+        # whatever the exchange raises, the line the watchdog holds still goes out
+        try:
+            return what()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            watchdog.leave("%s: %s" % (type(e).__name__, str(e)[:300]))
+
+    if world == 1:
+        result = measure(sortfirst)
+    elif sortfirst:
+        # Sort-first is the headline: the other split first (every rank draws whole frames of its own,
+        # no exchange).  It is reported beside the headline, and it is the line of a run whose band
+        # exchange fails or hangs.
         frame_parallel = measure_frame_parallel(api, torch, dist, scene, local_rank, world, rank, args.steps, args.warmup,
                                                 min(max(0, args.prewarm_frames), 512), stat_device)
         watchdog = Watchdog(args.watchdog_seconds, rank)
-        watchdog.start(fallback_line(args, scene, world, frame_parallel, "") if rank == 0 else None)
-    try:
-        run_headline(args, api, torch, dist, scenes, shard, scene, world, rank, local_rank, rehearsal, stat_device, sortfirst,
-                     scissor, make_drawer, frame_parallel)
-    except Exception as e:  # noqa: BLE001 (whatever the exchange raises, the frame-parallel line still goes out)
-        if watchdog is None:
-            raise
-        import traceback
-        traceback.print_exc()
-        watchdog.leave("%s: %s" % (type(e).__name__, str(e)[:300]))
-    if watchdog is not None:
+        watchdog.start(fallback_line(args, scene, world, frame_parallel, "") if rank == 0 else None, "sortfirst")
+        result = guarded(watchdog, lambda: measure(True))
         watchdog.finish()
+        if rank == 0:
+            result["frame_parallel"] = frame_parallel  # (measured before the headline, on a context of its own)
+    else:
+        # Frame-parallel is the headline; the sort-first split of the same frames as a further key.
+        result = measure(False)
+        if not args.no_depth_variant:
+            watchdog = Watchdog(args.watchdog_seconds, rank)
+            watchdog.start(result if rank == 0 else None, "sort_first")
+            sf = guarded(watchdog, lambda: measure(True))
+            watchdog.finish()
+            if rank == 0:
+                keep = ("value", "unit", "steps", "warmup", "ms_per_step", "scaling", "frames_per_sec", "gather_ms", "bands",
+                        "band_tuning", "per_rank", "stale_bands_in_timed_region", "kernels_ms", "sustained", "check", "invalid")
+                result["sort_first"] = {k: sf[k] for k in keep if k in sf}
+                result["sort_first"]["parallelism"] = sf["config"]["parallelism"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
 
 
-def run_headline(args, api, torch, dist, scenes, shard, scene, world, rank, local_rank, rehearsal, stat_device, sortfirst,
-                 scissor, make_drawer, frame_parallel):
+def run_measurement(args, api, torch, dist, shard, scene, world, rank, local_rank, rehearsal, stat_device, sortfirst,
+                    scissor, make_drawer):
+    """One split of the workload over the ranks, measured under the contract (warm-up, exactly
+    --steps steps between fences and barriers, the maximum over the ranks): returns the line's
+    fields on rank 0, None elsewhere."""
     width, height = scene.size
     n_prims = scene.n_triangles
     if os.environ.get("SXE_BENCH_TEST_FAIL") == "raise" and sortfirst and world > 1 and rank == world - 1:
@@ -619,14 +653,8 @@ def run_headline(args, api, torch, dist, scenes, shard, scene, world, rank, loca
                 result[key] = measure()
             except Exception as e:  # noqa: BLE001
                 result[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if frame_parallel is not None and rank == 0:
-        result["frame_parallel"] = frame_parallel  # (measured before the headline, on a context of its own)
     pipe = None
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+    return result
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ def test_sort_first_bench_with_ranks_sharing_one_gpu(world, config):
     env = dict(os.environ, SXE_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--config", str(config), "--scale", "0.25", "--prewarm-frames", "8", "--check"]
+           "--config", str(config), "--scale", "0.25", "--prewarm-frames", "8", "--check", "--mode", "sortfirst"]
     run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-2000:]
     line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
@@ -56,7 +56,7 @@ def test_a_band_exchange_that_fails_leaves_the_frame_parallel_line(failure):
     env = dict(os.environ, SXE_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", SXE_BENCH_TEST_FAIL=failure)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--config", "3", "--scale", "0.25", "--prewarm-frames", "8", "--watchdog-seconds", "25"]
+           "--config", "3", "--scale", "0.25", "--prewarm-frames", "8", "--watchdog-seconds", "25", "--mode", "sortfirst"]
     run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr[-2000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
@@ -65,3 +65,42 @@ def test_a_band_exchange_that_fails_leaves_the_frame_parallel_line(failure):
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["steps"] == 6 and out["warmup"] == 2
     assert out["value"] > 0 and out["config"]["parallelism"] == "frame-parallel2"
     assert out["sortfirst"]["error"]
+
+
+def _bench(world, extra, env_extra=None, timeout=600):
+    env = dict(os.environ, SXE_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+           "--scale", "0.25", "--prewarm-frames", "8"] + extra
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_default_split_of_config3_is_frame_parallel_with_sort_first_beside_it():
+    """Without --mode, N ranks draw whole frames of config 3 each (the headline, weak scaling, with the
+    kernel figures of whole frames), and the sort-first split of the same frames is a further key;
+    the 8K frame of config 4 is split sort-first."""
+    out = _bench(2, ["--config", "3", "--check"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "frame-parallel2"
+    assert out["config"]["frames_per_step"] == 2 and out["steps"] == 6 and out["warmup"] == 2
+    assert out["check"] == {"color_equal": True, "depth_equal": True}
+    assert out["roofline"]["kernel"] in ("k_raster_shade", "k_setup") and 0.0 < out["roofline"]["frac"] <= 1.0
+    sf = out["sort_first"]
+    assert sf["scaling"] == "strong" and sf["value"] > 0 and sf["steps"] == 6 and sf["parallelism"].startswith("sortfirst-bands2")
+    assert sf["check"] == {"color_equal": True, "depth_equal": True} and len(sf["per_rank"]) == 2
+    out4 = _bench(2, ["--config", "4"])
+    assert out4["scaling"] == "strong" and out4["frame_parallel"]["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("failure", ["raise", "hang"])
+def test_a_failing_exchange_beside_a_frame_parallel_headline(failure):
+    """The sort-first measurement beside a frame-parallel headline fails: the headline is complete and
+    goes out, the failure is recorded under the key."""
+    out = _bench(2, ["--config", "3", "--watchdog-seconds", "25"], {"SXE_BENCH_TEST_FAIL": failure}, timeout=300)
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["sort_first"]["error"] and "value" not in out["sort_first"]
