@@ -170,7 +170,7 @@ def fallback_line(args, scene, world, fp, why):
     """The line of a sort-first run whose band exchange did not come through: the frame-parallel
     measurement taken before it, under the same contract, and what happened to the other."""
     width, height = scene.size
-    return {"metric": "triangles_per_sec", "value": fp["value"], "unit": "triangles/s", "n_gpus": world,
+    line = {"metric": "triangles_per_sec", "value": fp["value"], "unit": "triangles/s", "n_gpus": world,
             "steps": fp["steps"], "warmup": fp["warmup"], "ms_per_step": fp["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32+i64", "data": "synthetic",
             "frames_per_sec": fp["frames_per_sec"],
@@ -180,6 +180,11 @@ def fallback_line(args, scene, world, fp, why):
             "roofline": None, "cpu_baseline": None,
             "sortfirst": {"error": why, "note": "the sort-first measurement did not finish; this line is the frame-parallel "
                                                 "split of the same workload, measured before it"}}
+    if args.scale != 1.0:
+        line["invalid"] = "scaled-down debug run"
+    if os.environ.get("SXE_BENCH_REHEARSAL", "") == "1":
+        line["invalid"] = "rehearsal: ranks share GPUs, exchange over gloo through host memory"
+    return line
 
 
 class Watchdog:

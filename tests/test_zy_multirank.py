@@ -64,7 +64,7 @@ def test_a_band_exchange_that_fails_leaves_the_frame_parallel_line(failure):
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["steps"] == 6 and out["warmup"] == 2
     assert out["value"] > 0 and out["config"]["parallelism"] == "frame-parallel2"
-    assert out["sortfirst"]["error"]
+    assert out["sortfirst"]["error"] and out["invalid"].startswith("rehearsal")
 
 
 def _bench(world, extra, env_extra=None, timeout=600):
